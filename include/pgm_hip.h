@@ -1,0 +1,155 @@
+/*
+ * pgm_hip.h — C ABI of the MI355X (gfx950) accelerator for ProGraphMSA's hot path.
+ *
+ * The reference (acg-team/ProGraphMSA) has no plugin/FFI layer; its seams are three C++
+ * functions.  Each entry point below replaces one of them (reference file:line cited per
+ * function).  Plain C types only: pointers + sizes, caller-allocated outputs, `int`
+ * status return (0 = PGM_OK).  The library is libpgm_hip.so (prographmsa_amd/csrc).
+ *
+ * The identical structs are consumed by the test-only CPU oracle (oracle/pgm_oracle.c),
+ * which exports the same functions under the `pgmo_` prefix.
+ */
+#ifndef PGM_HIP_H_
+#define PGM_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------ */
+#define PGM_OK 0
+#define PGM_ERR_INVALID 1    /* bad argument (null pointer, n < 2, dim mismatch ...)        */
+#define PGM_ERR_DEVICE 2     /* HIP runtime error; see pgm_last_error()                     */
+#define PGM_ERR_BACKTRACK 3  /* reference: error("backtracking failed") GraphAlign.h:410    */
+#define PGM_ERR_NOMEM 4
+
+#define PGM_GAP 0xFFFFFFFFu  /* (index_t)-1 in the reference's mappings                     */
+
+/* ---- flattened reference types ------------------------------------------------------- */
+
+/* Graph<ALPHABET> (reference src/Graph.h:31-33).  `sites` is the Eigen profile matrix
+ * (dim x n, column-major, double; columns 0 and n-1 are the zero START/END columns).
+ * `e_*` is the row-major CSR of `edges(to,from)`: row = node, col = predecessor (ascending),
+ * value = min(cost,1e4f)-1e4f exactly as stored by Graph::setEdgesFromMap (Graph.h:85).
+ * `r_*` is the CSR of `repeats(to,from)` (value = repeat-unit count); r_rowptr may be NULL
+ * when the graph has no tandem-repeat edges.  Iteration order of PredIterator (Graph.h:196):
+ * all e_ entries of the row, then all r_ entries. */
+typedef struct pgm_graph {
+    uint32_t n;
+    uint32_t dim;
+    const double *sites;
+    const int32_t *e_rowptr; /* n+1 */
+    const uint32_t *e_col;
+    const float *e_val;
+    const int32_t *r_rowptr; /* n+1 or NULL */
+    const uint32_t *r_col;
+    const uint32_t *r_units;
+} pgm_graph;
+
+/* The members of Model<ALPHABET> (reference src/Model.h:8-24) that reach alignGraphs:
+ * M = diag(pi)*P(d), dim x dim column-major double; pi, dim doubles. */
+typedef struct pgm_model {
+    const double *M;
+    const double *pi;
+} pgm_model;
+
+/* DynProgScores<ALPHABET> (reference src/GraphAlign.h:133-142), computed by the host caller
+ * (it needs averageAlignmentLength and cmdlineopts) and passed by value. */
+typedef struct pgm_scores {
+    float gap_init, gap_extend, match_init, end_match, end_gap, end_skip;
+    float start_gap, start_init, repeat_init, repeat_ext;
+} pgm_scores;
+
+/* AlignmentResult<ALPHABET> (reference src/GraphAlign.h:6-12).  map1/map2 are caller
+ * allocated with capacity n1+n2 (the reference reserves the same, GraphAlign.h:297-298);
+ * `len` entries are valid, PGM_GAP marks a gap, entry 0 is (0,0), the last (n1-1,n2-1). */
+typedef struct pgm_align_out {
+    float score;
+    uint32_t n_tr_indels;
+    uint32_t len;
+    int32_t status; /* PGM_OK or PGM_ERR_BACKTRACK for this job */
+    uint32_t *map1;
+    uint32_t *map2;
+} pgm_align_out;
+
+typedef struct pgm_ctx pgm_ctx;
+typedef struct pgm_align_batch pgm_align_batch;
+
+/* ---- context ------------------------------------------------------------------------ */
+int pgm_device_count(void);
+int pgm_ctx_create(int device, pgm_ctx **out);
+void pgm_ctx_destroy(pgm_ctx *ctx);
+const char *pgm_last_error(void);
+/* name of the device ("gfx950...") and CU count, for logs */
+int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count);
+
+/* ---- (B1) alignGraphs  — replaces reference src/GraphAlign.h:200-534 ------------------
+ * One call = njobs independent alignGraphs(g1[i], g2[i], model[i]) evaluations (the
+ * reference calls it once per internal guide-tree node, ProgressiveAlignment.h:439, and
+ * once per child in early refinement, :170).  Emission scores + ls_log (GraphAlign.h:146-163,
+ * ls_log.h:22-59), border init (:205-234), fill (:238-260), end node (:264-280) and the
+ * traceback incl. markAlternativePath (:166-198, :285-521) all run on the GPU. */
+int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
+                           const pgm_graph *const *g2, const pgm_model *const *model,
+                           const pgm_scores *scores, pgm_align_out *out);
+
+/* Staged form of the same call (what pgm_align_graphs_batch does internally):
+ *   create  : flatten + upload every job's inputs to HBM, allocate the DP storage
+ *   run     : launch prep + fill + traceback kernels on the context's stream (asynchronous)
+ *   fetch   : wait, copy score / mappings back into caller memory
+ * bench.py times `run` with the inputs already resident. */
+int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
+                           const pgm_graph *const *g2, const pgm_model *const *model,
+                           const pgm_scores *scores, pgm_align_batch **out);
+int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b);
+int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out);
+void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);
+/* Σ (n1-2)(n2-2) over the jobs of the batch (the GCUPS numerator). */
+uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
+/* Run the batch `reps` times back to back and return the mean device time in milliseconds of
+ * each kernel stage, measured with HIP events on the context's stream. */
+int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
+                         float *ms_fill, float *ms_traceback);
+/* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
+ * column-major, element (y,x) at y + x*n1).  Only rows < n1-1 and columns < n2-1 are
+ * defined (the END row/column are never written by the reference's fill either).
+ * Any of M,X,Y,W may be NULL.  S is the emission matrix of GraphAlign.h:146-163. */
+int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job, float *M,
+                                  float *X, float *Y, float *W, float *S);
+
+/* ---- (B2) DistanceFactoryAlign::alignPair — replaces reference
+ * src/DistanceFactoryAlign.h:59-127 (called from computePwDistances, :29-56).
+ * syms: concatenated sequences already mapped through ALPHABET::value() with negative
+ * values replaced by 20 (the reference's quirk, :72,79); offs[nseq+1] delimits them.
+ * score: (dim+1)x(dim+1) int32 column-major scoring matrix (DistanceFactoryAlign.cpp).
+ * For pair p = (pi[p], pj[p]) with seq1 = sequence pi, seq2 = sequence pj the call returns
+ * counts[p*dim*dim + s1 + dim*s2] (the reference's CountMatrix counts(s1,s2), column-major)
+ * and gaps[p] (number of gap openings on the traceback path). */
+int pgm_nw_pairs_batch(pgm_ctx *ctx, uint32_t dim, const int32_t *score, int32_t gap_open,
+                       int32_t gap_extend, uint32_t nseq, const int8_t *syms,
+                       const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
+                       const uint32_t *pj, int32_t *counts, uint32_t *gaps);
+/* Device-time of the NW kernels of the last pgm_nw_pairs_batch call on this context (ms). */
+float pgm_nw_last_kernel_ms(pgm_ctx *ctx);
+
+/* ---- (B3) CSProfile::createProfile — replaces reference src/CSProfile.cpp:175-225 ------
+ * load: K context profiles with `ncols` window columns.  lprofiles: K x ncols x 21 doubles
+ * (weights already applied, last entry of each row = 0, CSProfile.cpp:157-162), row-major
+ * [k][col][symbol]; centre: K x 20 doubles = profiles_k.row(center); priors: K doubles
+ * (= log(PRIOR)).  create: for each sequence (symbols 0..19, 20 = invalid) writes the
+ * 20 x (L+2) column-major double profile of Model<AA>::Profile into out + out_offs[s].
+ * tau[s] = model.divergence/0.8; pi = model.pi (20); p_uniform = model.P * (1/20) (20). */
+int pgm_csprofile_load(pgm_ctx *ctx, uint32_t K, uint32_t ncols, const double *lprofiles,
+                       const double *centre, const double *priors);
+int pgm_csprofile_create_batch(pgm_ctx *ctx, uint32_t nseq, const int8_t *syms,
+                               const uint32_t *offs, const double *tau, const double *pi,
+                               const double *p_uniform, double *out, const uint64_t *out_offs);
+float pgm_csprofile_last_kernel_ms(pgm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGM_HIP_H_ */

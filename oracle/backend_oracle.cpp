@@ -1,0 +1,45 @@
+// backend_oracle.cpp — TEST INFRASTRUCTURE ONLY.  Binds the host call surface
+// (prographmsa_amd/host) to the CPU oracle so that the scaffolding + oracle can be pinned against
+// the reference binary's FASTA output (tests/test_oracle_golden.py).  Never linked into the product.
+#include "../prographmsa_amd/host/pgm_host.h"
+
+extern "C" {
+int pgmo_align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out);
+int pgmo_nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t gap_open, int32_t gap_extend, uint32_t nseq,
+                        const int8_t *syms, const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
+                        const uint32_t *pj, int32_t *counts, uint32_t *gaps);
+int pgmo_csprofile_create(uint32_t K, uint32_t ncols, const double *lprofiles, const double *centre,
+                          const double *priors, const int8_t *seq, uint32_t L, double tau, const double *pi,
+                          const double *p_uniform, double *out);
+}
+
+namespace pgm {
+namespace {
+struct OracleBackend : Backend {
+    const char *name() const override { return "oracle"; }
+    void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) override {
+        pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out);
+    }
+    void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
+                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
+                        uint32_t *gaps) override {
+        if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps) != PGM_OK)
+            error("error while backtracking");
+    }
+    void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
+                                const double *tau, const double *pi, const double *p_uniform, double *out,
+                                const uint64_t *out_offs) override {
+        for (uint32_t s = 0; s < nseq; ++s)
+            pgmo_csprofile_create((uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(), lib.centre().data(),
+                                  lib.priors().data(), syms + offs[s], offs[s + 1] - offs[s], tau[s], pi,
+                                  p_uniform + (size_t)s * 20, out + out_offs[s]);
+    }
+};
+}  // namespace
+Backend &default_backend() {
+    static OracleBackend be;
+    return be;
+}
+}  // namespace pgm

@@ -1,0 +1,254 @@
+// distance.cpp — pairwise distances and the BioNJ guide tree for the `-a` path
+// (reference src/DistanceFactoryAlign.{h,cpp}, DistanceFactoryML.{h,cpp}, TreeNJ.{h,cpp}).
+// The O(L^2) Needleman-Wunsch of every pair (alignPair) runs behind the C ABI
+// (pgm_nw_pairs_batch); ML distance estimation and neighbour joining stay on the host.
+#include "pgm_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <fstream>
+
+namespace pgm {
+
+// ---- DistanceFactoryML ---------------------------------------------------------------------
+static void consts(const Alphabet &a, double &DIST_MAX, double &VAR_MAX, double &VAR_MIN) {  // DistanceFactoryML.cpp
+    if (a.kind == ALPHA_AA) { DIST_MAX = 2.2; VAR_MAX = 1e3; VAR_MIN = 1e-5; }
+    else { DIST_MAX = 5.2; VAR_MAX = 5e3; VAR_MIN = 1e-5; }
+}
+
+static void matmul(const std::vector<double> &A, const std::vector<double> &B, int n, std::vector<double> &C) {
+    C.assign((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+            double b = B[k + n * j];
+            for (int i = 0; i < n; ++i) C[i + n * j] += A[i + n * k] * b;
+        }
+}
+
+distvar_t DistanceFactoryML::computeMLDist(const std::vector<int32_t> &counts, index_t gaps, double seqlen, double dist0,
+                                           double var0) const {  // DistanceFactoryML.h:66-135
+    const int n = alphabet.DIM;
+    double DIST_MAX, VAR_MAX, VAR_MIN;
+    consts(alphabet, DIST_MAX, VAR_MAX, VAR_MIN);
+    const double EPSILON = 1e-5;
+    const index_t MAXITER = 20;
+    double dist_min = 0, dist_max = INFINITY;
+    double dist = dist0, var = var0;
+    double delta = 1;
+    index_t iteration = 0;
+    std::vector<double> pp, ppp;
+    while (std::abs(delta) > EPSILON) {
+        if (iteration > MAXITER) {
+            if (dist_max == INFINITY) { dist = DIST_MAX; var = VAR_MAX; }
+            else { dist = dist0; var = var0; }
+            break;
+        }
+        Model model = model_factory->getModel(dist);
+        const std::vector<double> &p = model.P;
+        matmul(model.Q, p, n, pp);
+        matmul(model.Q, pp, n, ppp);
+        double f = 0, ff = 0;
+        for (size_t i = 0; i < p.size(); ++i) {
+            double c = counts[i];
+            f += c * pp[i] / p[i];
+            ff += (c * (ppp[i] * p[i] - pp[i] * pp[i])) / (p[i] * p[i]);
+        }
+        if (cmdlineopts.mldist_gap_flag) {
+            double grate = cmdlineopts.indel_rate * seqlen * dist;
+            f += (-grate + gaps) / dist;
+            ff += -(double)gaps / (dist * dist);
+        }
+        var = -1.0 / ff;
+        if (f > 0) dist_min = std::max(dist_min, dist);
+        else dist_max = std::min(dist_max, dist);
+        double new_dist = dist - f / ff;
+        if (!(new_dist < dist_max && new_dist > dist_min)) {
+            double upper = (dist_max == INFINITY) ? dist * 3 : dist_max;
+            new_dist = (upper + dist_min) / 2.0;
+        }
+        delta = 1.0 - new_dist / dist;
+        dist = new_dist;
+        ++iteration;
+    }
+    return distvar_t{dist, var};
+}
+
+distvar_t DistanceFactoryML::computeDistance(const std::vector<int32_t> &counts, index_t gaps, double seqlen) const {
+    const int n = alphabet.DIM;  // DistanceFactoryML.h:137-190
+    double DIST_MAX, VAR_MAX, VAR_MIN;
+    consts(alphabet, DIST_MAX, VAR_MAX, VAR_MIN);
+    double ident = 0, total = 0;
+    for (int i = 0; i < n; ++i) ident += counts[i + n * i];
+    for (int32_t c : counts) total += c;
+    double dist0 = 1.0 - ident / total;
+    double dist, var;
+    if (cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag) {
+        if (total == 0 || dist0 > 0.85) { dist = dist0 = DIST_MAX; var = VAR_MAX; }
+        else { dist = dist0 = -std::log(1.0 - dist0 - 0.2 * dist0 * dist0); var = dist / total; }
+        if (total > 0 && ident != total) {
+            distvar_t dv = computeMLDist(counts, gaps, seqlen, dist, var);
+            dist = dv.dist;
+            var = dv.var;
+        }
+    } else {
+        if (total == 0) { dist = dist0 = 1.0; var = VAR_MAX; }
+        else { dist = dist0; var = dist0 / total; }
+    }
+    if (!(dist < DIST_MAX)) { dist = DIST_MAX; var = VAR_MAX; }
+    if (dist > cmdlineopts.cutoff_dist) dist = cmdlineopts.cutoff_dist;
+    if (var < VAR_MIN) var = VAR_MIN;
+    if (!(var < VAR_MAX)) var = VAR_MAX;
+    return distvar_t{dist, var};
+}
+
+// ---- DistanceFactoryAlign ---------------------------------------------------------------------
+DistanceFactoryAlign::DistanceFactoryAlign(const Alphabet &a, const ModelFactory *mf) : DistanceFactoryML(a, mf) {
+    const int sd = a.DIM + 1;  // initMatrix (DistanceFactoryAlign.cpp:5-35, 38-235)
+    std::string file = data_dir() + (a.kind == ALPHA_AA ? "/nw_aa.imat" : "/nw_codon.imat");
+    std::ifstream in(file.c_str());
+    int r = 0, c = 0;
+    in >> r >> c;
+    if (!in || r != sd || c != sd) error("cannot read NW scoring matrix %s", file.c_str());
+    scoring_matrix_.resize((size_t)sd * sd);
+    for (int32_t &v : scoring_matrix_) in >> v;
+    gap_open = -10;
+    gap_extend = -2;
+}
+
+DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::string, sequence_t> &sequences,
+                                                        const std::vector<std::string> &order) {
+    const uint32_t n = (uint32_t)order.size();
+    const uint32_t D = (uint32_t)alphabet.DIM;
+    DistanceMatrix distances((int)n);
+    // symbols: value(), negative -> 20 for every alphabet (the reference's quirk, DistanceFactoryAlign.h:72,79)
+    std::vector<int8_t> syms;
+    std::vector<uint32_t> offs(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const sequence_t &s = sequences.at(order[i]);
+        for (int8_t c : s) {
+            int v = alphabet.value(c);
+            syms.push_back((int8_t)(v < 0 ? 20 : v));
+        }
+        offs[i + 1] = (uint32_t)syms.size();
+    }
+    std::vector<uint32_t> pi, pj;
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = i + 1; j < n; ++j) { pi.push_back(i); pj.push_back(j); }
+    const uint32_t np = (uint32_t)pi.size();
+    std::vector<int32_t> counts((size_t)np * D * D);
+    std::vector<uint32_t> gaps(np);
+    Backend &be = default_backend();
+    for (uint32_t p = 0; p < np; ++p)
+        be.cells_nw += (uint64_t)(offs[pi[p] + 1] - offs[pi[p]]) * (offs[pj[p] + 1] - offs[pj[p]]);
+    auto t0 = std::chrono::steady_clock::now();
+    be.nw_pairs_batch(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), np, pi.data(),
+                      pj.data(), counts.data(), gaps.data());
+    be.seconds_nw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<int32_t> c((size_t)D * D);
+    for (uint32_t p = 0; p < np; ++p) {
+        std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
+        double L1 = offs[pi[p] + 1] - offs[pi[p]], L2 = offs[pj[p] + 1] - offs[pj[p]];
+        distvar_t dv = computeDistance(c, gaps[p], (L1 + L2) / 2.0);
+        distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
+        distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
+    }
+    return distances;
+}
+
+// ---- BioNJ (TreeNJ.cpp:22-29, 132-281; no fixed-topology plan) --------------------------------------
+static double support(double d) {
+    double s = 1.0 - std::exp(-std::log(2.0) * d / cmdlineopts.edge_halflife);
+    s = std::min(1.0, std::max(0.0, s));
+    if (std::isnan(s)) s = 0.0;
+    return s;
+}
+
+PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
+    const double MIN_DIST = 1e-4, MIN_VAR = 1e-5;
+    std::vector<PhyTree *> subtrees;
+    for (const std::string &s : seqs_order) subtrees.push_back(new PhyTree(s));
+    for (int dim = (int)seqs_order.size(); dim > 3; --dim) {
+        for (double &d : dist.distances) d = std::max(d, MIN_DIST);
+        for (double &v : dist.variances) v = std::max(v, MIN_VAR);
+        for (int i = 0; i < dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
+        std::vector<double> sums(dim, 0.0);  // colwise sums
+        for (int j = 0; j < dim; ++j) {
+            double s = 0;
+            for (int i = 0; i < dim; ++i) s += dist.D(i, j);
+            sums[j] = s;
+        }
+        // Q = 0.5 d - 0.5/(dim-2) (S + S^T); minCoeff scans column-major (row index fastest) and keeps the first minimum
+        int index1 = 0, index2 = 0;
+        double min = INFINITY;
+        for (int col = 0; col < dim; ++col)
+            for (int row = 0; row < dim; ++row) {
+                if (row == col) continue;
+                double q = 0.5 * dist.D(row, col) - (0.5 / (dim - 2.0)) * (sums[col] + sums[row]);
+                if (q < min) { min = q; index2 = row; index1 = col; }
+            }
+        if (index2 < index1) std::swap(index1, index2);
+        std::string name1 = seqs_order[index1], name2 = seqs_order[index2];
+        double dist1 = (dist.D(index1, index2) + (sums[index1] - sums[index2]) / (dim - 2.0)) / 2.0;
+        dist1 = std::min(std::max(dist1, MIN_DIST), dist.D(index1, index2));
+        double dist2 = std::max(dist.D(index2, index1) - dist1, MIN_DIST);
+        double vsum = 0;
+        for (int i = 0; i < dim; ++i) vsum += dist.V(index2, i) - dist.V(index1, i);
+        double lambda = .5 + vsum / (2 * (dim - 2) * dist.V(index1, index2));
+        if (std::isnan(lambda)) lambda = .5;
+        else lambda = std::min(std::max(0.0, lambda), 1.0);
+
+        DistanceMatrix red(dim - 1);
+        auto old = [&](int i) { return i < index2 ? i : i + 1; };  // reduce(index2)
+        for (int i = 0; i < dim - 1; ++i)
+            for (int j = 0; j < dim - 1; ++j) { red.D(i, j) = dist.D(old(i), old(j)); red.V(i, j) = dist.V(old(i), old(j)); }
+        for (int i = 0; i < dim - 1; ++i) {
+            int o = old(i);
+            double nd = lambda * (dist.D(index1, o) - dist1) + (1.0 - lambda) * (dist.D(index2, o) - dist2);
+            double nv = lambda * dist.V(index1, o) + (1.0 - lambda) * dist.V(index2, o) - lambda * (1.0 - lambda) * dist.V(index1, index2);
+            if (i == index1) { nd = 0; nv = 0; }
+            red.D(index1, i) = red.D(i, index1) = nd;
+            red.V(index1, i) = red.V(i, index1) = nv;
+        }
+        dist = red;
+        seqs_order.erase(seqs_order.begin() + index2);
+        seqs_order[index1] = name1 + "," + name2;
+        PhyTree *tree = new PhyTree(seqs_order[index1]);
+        tree->addChild(subtrees[index1], dist1, support(dist1));
+        tree->addChild(subtrees[index2], dist2, support(dist2));
+        subtrees.erase(subtrees.begin() + index2);
+        subtrees[index1] = tree;
+    }
+    PhyTree *tree = new PhyTree("root");
+    if (seqs_order.size() == 2) {
+        double d = dist.D(0, 1) / 2;
+        tree->addChild(subtrees[0], d, support(d));
+        tree->addChild(subtrees[1], d, support(d));
+    } else {
+        double d0 = (dist.D(0, 1) + dist.D(0, 2) - dist.D(1, 2)) / 2.0;
+        d0 = std::min(std::max(d0, MIN_DIST), std::min(dist.D(1, 0), dist.D(2, 0)));
+        double d1 = std::max(dist.D(1, 0) - d0, MIN_DIST);
+        double d2 = std::max(dist.D(2, 0) - d0, MIN_DIST);
+        PhyTree *tree2 = new PhyTree("root2");
+        tree2->addChild(subtrees[0], d0, support(d0));
+        tree2->addChild(subtrees[1], d1, support(d1));
+        tree->addChild(subtrees[2], d2 / 2, support(d2));
+        tree->addChild(tree2, d2 / 2, support(d2));
+    }
+    return tree;
+}
+
+PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf) {
+    if (seqs.size() < 2) error("cannot construct tree from < 2 sequences");
+    if (!cmdlineopts.nwdist_flag)
+        error("initial guide tree: only -a/--nwdist (DistanceFactoryAlign) is built here; pass --tree or -a");
+    std::vector<std::string> order;
+    for (const auto &kv : seqs) order.push_back(kv.first);  // std::map key order (TreeNJ.h:34-39)
+    DistanceFactoryAlign df(a, mf);
+    DistanceMatrix dist = df.computePwDistances(seqs, order);
+    for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
+    PhyTree *tree = buildNJTree(order, dist);
+    return midpointRoot(tree);
+}
+
+}  // namespace pgm

@@ -1,0 +1,316 @@
+// graph_align.cpp — host side of reference src/GraphAlign.h: DynProgScores (:98-143),
+// the alignGraphs call surface (:200-534, executed by the backend behind the C ABI) and
+// mergeGraphs (:550-727) with the reference's quirks kept.
+#include "pgm_host.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+namespace pgm {
+
+#define LOG(x) (std::log(x) / std::log(2))  // GraphAlign.h:46-48 (USE_LS_LOG build)
+
+static double averageAlignmentLengthRec(const Graph &g, index_t current, std::vector<double> &cache) {
+    // GraphAlign.h:56-80; recursion depth can reach n, so an explicit stack is used (same values).
+    struct Frame { index_t node; Graph::PredIterator it; double sum; index_t paths; };
+    std::vector<Frame> st;
+    if (cache[current] != -1.0) return cache[current];
+    st.push_back(Frame{current, g.getPreds(current, INFINITY, INFINITY), 0.0, 0});
+    while (!st.empty()) {
+        Frame &f = st.back();
+        bool descended = false;
+        while (f.it) {
+            index_t xp = *f.it;
+            if (f.it.value() == 0.0) {
+                if (cache[xp] == -1.0) {
+                    st.push_back(Frame{xp, g.getPreds(xp, INFINITY, INFINITY), 0.0, 0});
+                    descended = true;
+                    break;
+                }
+                double res = cache[xp];
+                if (res >= 0.0) { f.sum += res + 1.0; ++f.paths; }
+            }
+            ++f.it;
+        }
+        if (descended) continue;
+        cache[f.node] = f.paths > 0 ? f.sum / f.paths : -2.0;
+        st.pop_back();
+    }
+    return cache[current];
+}
+
+double averageAlignmentLength(const Graph &g) {  // GraphAlign.h:82-96
+    if (g.size() == 0) return 0;
+    std::vector<double> cache(g.size(), -1.0);
+    cache[0] = 0;
+    return averageAlignmentLengthRec(g, g.size() - 1, cache);
+}
+
+pgm_scores DynProgScores(const Graph &g1, const Graph &g2, const Model &model) {  // GraphAlign.h:100-131
+    const double l1 = averageAlignmentLength(g1);
+    const double l2 = averageAlignmentLength(g2);
+    const double exp_length = std::max(l1, l2) * std::exp(model.distance * cmdlineopts.indel_rate * (model.epsilon / (1.0 - model.epsilon) + 1.0));
+    const double nu = 2.0 / (2.0 + l1 + l2);
+    double ttau = 1.0 / (1.0 + exp_length);
+    if (model.epsilon + ttau >= 1.0) ttau = (1.0 - model.epsilon) / 2.0;
+    const double tau = ttau;
+    const double E = cmdlineopts.end_indel_prob;
+    pgm_scores s;
+    s.gap_init = (float)LOG(model.delta * (1.0 - model.epsilon - tau) / (1.0 - nu));
+    s.gap_extend = (float)LOG(model.epsilon / (1.0 - nu));
+    s.match_init = (float)LOG((1.0 - 2.0 * model.delta) * (1.0 - tau) / (1.0 - nu) / (1.0 - nu));
+    s.end_skip = (float)LOG(tau);
+    if (E >= 0 && E <= 1) {
+        s.end_match = (float)LOG(tau * (1.0 - E) / (1.0 - 2.0 * model.delta) / (1.0 - tau));
+        s.end_gap = (float)LOG(tau * E / 2.0 / (1.0 - model.epsilon - tau) / model.delta);
+        s.start_gap = (float)LOG(E / 2.0 * (1.0 - model.epsilon - tau) / (1.0 - E) / (1.0 - nu));
+        s.start_init = (float)LOG((1.0 - tau) * (1.0 - E));
+    } else {
+        s.end_match = (float)LOG(tau / (1.0 - tau));
+        s.end_gap = (float)LOG(tau / (1.0 - model.epsilon - tau));
+        s.start_gap = (float)LOG(model.delta * (1.0 - model.epsilon - tau) / (1.0 - nu));
+        s.start_init = (float)LOG(1.0 - tau);
+    }
+    const double repeat_prob = 1.0 - std::exp(-model.distance * cmdlineopts.repeat_rate);
+    s.repeat_init = (float)-LOG(std::min<double>(1, repeat_prob / (1 - repeat_prob) * (1 - cmdlineopts.repeatext_prob)));
+    s.repeat_ext = (float)-LOG(std::min<double>(1, std::max<double>(0, cmdlineopts.repeatext_prob)));
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Job dump: a flat binary record per alignGraphs call so that tests and bench.py can replay the
+// exact jobs of a progressive pass through the C ABI (format documented in prographmsa_amd/jobs.py).
+static std::string g_dump_path;
+void set_job_dump(const std::string &path) {
+    g_dump_path = path;
+    if (!path.empty()) { FILE *f = fopen(path.c_str(), "wb"); if (f) fclose(f); }
+}
+static void dump_graph(FILE *f, const pgm_graph &g) {
+    uint32_t hdr[4] = {g.n, g.dim, (uint32_t)g.e_rowptr[g.n], g.r_rowptr ? (uint32_t)g.r_rowptr[g.n] : 0u};
+    fwrite(hdr, 4, 4, f);
+    fwrite(g.sites, 8, (size_t)g.n * g.dim, f);
+    fwrite(g.e_rowptr, 4, g.n + 1, f);
+    fwrite(g.e_col, 4, hdr[2], f);
+    fwrite(g.e_val, 4, hdr[2], f);
+    if (hdr[3]) {
+        fwrite(g.r_rowptr, 4, g.n + 1, f);
+        fwrite(g.r_col, 4, hdr[3], f);
+        fwrite(g.r_units, 4, hdr[3], f);
+    }
+}
+static void dump_job(const pgm_graph &g1, const pgm_graph &g2, const pgm_model &m, const pgm_scores &s) {
+    FILE *f = fopen(g_dump_path.c_str(), "ab");
+    if (!f) return;
+    uint32_t magic = 0x4a4d4750u;  // "PGMJ"
+    fwrite(&magic, 4, 1, f);
+    dump_graph(f, g1);
+    dump_graph(f, g2);
+    fwrite(m.M, 8, (size_t)g1.dim * g1.dim, f);
+    fwrite(m.pi, 8, g1.dim, f);
+    fwrite(&s, sizeof s, 1, f);
+    fclose(f);
+}
+
+std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1, const std::vector<const Graph *> &g2,
+                                              const std::vector<const Model *> &model) {
+    const uint32_t n = (uint32_t)g1.size();
+    std::vector<pgm_graph> f1(n), f2(n);
+    std::vector<pgm_model> fm(n);
+    std::vector<pgm_scores> sc(n);
+    std::vector<const pgm_graph *> p1(n), p2(n);
+    std::vector<const pgm_model *> pm(n);
+    std::vector<pgm_align_out> out(n);
+    std::vector<AlignmentResult> res(n);
+    Backend &be = default_backend();
+    for (uint32_t i = 0; i < n; ++i) {
+        f1[i] = g1[i]->flat();
+        f2[i] = g2[i]->flat();
+        fm[i].M = model[i]->M.data();
+        fm[i].pi = model[i]->pi.data();
+        sc[i] = DynProgScores(*g1[i], *g2[i], *model[i]);
+        p1[i] = &f1[i]; p2[i] = &f2[i]; pm[i] = &fm[i];
+        res[i].mapping1.assign(g1[i]->size() + g2[i]->size(), 0);
+        res[i].mapping2.assign(g1[i]->size() + g2[i]->size(), 0);
+        out[i].map1 = res[i].mapping1.data();
+        out[i].map2 = res[i].mapping2.data();
+        out[i].len = 0;
+        out[i].status = 0;
+        be.cells_aligned += (uint64_t)(g1[i]->size() - 2) * (g2[i]->size() - 2);
+        if (!g_dump_path.empty()) dump_job(f1[i], f2[i], fm[i], sc[i]);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data());
+    be.seconds_align += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t i = 0; i < n; ++i) {
+        if (out[i].status != PGM_OK) error("backtracking failed");  // GraphAlign.h:410
+        res[i].score = out[i].score;
+        res[i].n_tr_indels = out[i].n_tr_indels;
+        res[i].mapping1.resize(out[i].len);
+        res[i].mapping2.resize(out[i].len);
+    }
+    return res;
+}
+
+AlignmentResult alignGraphs(const Graph &g1, const Graph &g2, const Model &model) {
+    return alignGraphsBatch({&g1}, {&g2}, {&model})[0];
+}
+
+// ---------------------------------------------------------------------------------------
+template <class MAP, class V>
+static inline void updateEdge(MAP &map, index_t from, index_t to, V cost) {  // GraphAlign.h:539-548
+    std::pair<index_t, index_t> i(to, from);
+    auto it = map.find(i);
+    if (it != map.end()) it->second = std::min(it->second, cost);
+    else map[i] = cost;
+}
+
+// y = P * g(:,i), P column-major
+// Association follows Eigen 3.0-3.2's column-major gemv (four columns at a time,
+// res += (c0 v0 + c1 v1) + (c2 v2 + c3 v3), leftover columns one by one): the binary's Eigen
+// version is not pinned, and only the last bit of a double depends on this.
+static void matvec(const std::vector<double> &P, const double *v, int n, std::vector<double> &out) {
+    out.assign(n, 0.0);
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {
+        const double *c0 = &P[(size_t)n * j], *c1 = c0 + n, *c2 = c1 + n, *c3 = c2 + n;
+        const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
+        for (int i = 0; i < n; ++i) out[i] += (c0[i] * v0 + c1[i] * v1) + (c2[i] * v2 + c3[i] * v3);
+    }
+    for (; j < n; ++j) {
+        const double vj = v[j];
+        const double *pc = &P[(size_t)n * j];
+        for (int i = 0; i < n; ++i) out[i] += pc[i] * vj;
+    }
+}
+static void normalize(std::vector<double> &p) {  // p.norm()==0 ? p : p.normalized()
+    double s = 0;
+    for (double v : p) s += v * v;
+    double nrm = std::sqrt(s);
+    if (nrm == 0) return;
+    double inv = 1.0 / nrm;  // Eigen 3.0-3.2 scalar quotient = multiplication by the reciprocal
+    for (double &v : p) v *= inv;
+}
+
+AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
+                            const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
+                            double support1, double support2) {
+    const int D = g1.dim();
+    const index_t NONE = (index_t)-1;
+    std::vector<std::vector<double>> nodes;
+    nodes.reserve(g1.size() + g2.size());
+    Graph::EdgeMap edges;
+    Graph::RepeatMap repeats;
+    AncestralResult result;
+    std::vector<double> p, q;
+
+    /* unify graphs (GraphAlign.h:569-620) */
+    for (index_t i1 = 0, i2 = 0, j = 0; j < mapping1.size(); ++j) {
+        index_t k1 = mapping1[j], k2 = mapping2[j];
+        if (k1 != NONE) {
+            for (; i1 != k1; ++i1) {
+                matvec(model1.P, g1.col(i1), D, p);
+                normalize(p);
+                nodes.push_back(p);
+                result.mapping1.push_back(i1);
+                result.mapping2.push_back(NONE);
+                result.is_matched.push_back(false);
+            }
+            ++i1;
+        }
+        if (k2 != NONE) {
+            for (; i2 != k2; ++i2) {
+                matvec(model1.P, g2.col(i2), D, p);  // model1 (sic), GraphAlign.h:591
+                normalize(p);
+                nodes.push_back(p);
+                result.mapping1.push_back(NONE);
+                result.mapping2.push_back(i2);
+                result.is_matched.push_back(false);
+            }
+            ++i2;
+        }
+        if (k1 != NONE && k2 != NONE) {
+            matvec(model1.P, g1.col(k1), D, p);
+            matvec(model2.P, g2.col(k2), D, q);
+            for (int a = 0; a < D; ++a) p[a] *= q[a];
+            normalize(p);
+            nodes.push_back(p);
+            result.mapping1.push_back(k1);
+            result.mapping2.push_back(k2);
+        } else if (k1 != NONE) {
+            matvec(model1.P, g1.col(k1), D, p);
+            normalize(p);
+            nodes.push_back(p);
+            result.mapping1.push_back(k1);
+            result.mapping2.push_back(NONE);
+        } else if (k2 != NONE) {
+            matvec(model2.P, g2.col(k2), D, p);
+            normalize(p);
+            nodes.push_back(p);
+            result.mapping1.push_back(NONE);
+            result.mapping2.push_back(k2);
+        } else {
+            error("error in mapping");
+        }
+        result.is_matched.push_back(true);
+    }
+
+    /* homologous path (GraphAlign.h:626-657) */
+    index_t last_xy = 0, last_x = 0, last_y = 0, last_mapped = 0;
+    for (index_t i = 1; i < nodes.size(); ++i) {
+        if (!result.is_matched[i]) continue;
+        updateEdge(edges, last_mapped, i, (dp_score_t)0);
+        last_mapped = i;
+        if (result.mapping1[i] != NONE && result.mapping2[i] != NONE) {
+            if (last_xy != i - 1) updateEdge(edges, last_xy, i, (dp_score_t)0);
+            last_xy = i;
+        }
+        if (result.mapping1[i] != NONE) {
+            if (last_y != i - 1) updateEdge(edges, last_y, i, (dp_score_t)0);
+            last_y = i;
+        }
+        if (result.mapping2[i] != NONE) {
+            if (last_x != i - 1) updateEdge(edges, last_x, i, (dp_score_t)0);
+            last_x = i;
+        }
+    }
+
+    /* inverse mappings (GraphAlign.h:661-673) */
+    std::vector<index_t> inv_mapping1(g1.size(), 0), inv_mapping2(g2.size(), 0);
+    for (index_t i = 0; i < result.mapping1.size(); ++i)
+        if (result.mapping1[i] != NONE) inv_mapping1[result.mapping1[i]] = i;
+    for (index_t i = 0; i < result.mapping2.size(); ++i)
+        if (result.mapping2[i] != NONE) inv_mapping2[result.mapping2[i]] = i;
+
+    /* penalties for unused edges (GraphAlign.h:677-681) */
+    double unused_prob1 = cmdlineopts.altsplice_prob + (1.0 - cmdlineopts.altsplice_prob) * (1.0 - support1);
+    dp_score_t unused_penalty1 = (dp_score_t)-LOG(unused_prob1);
+    double unused_prob2 = cmdlineopts.altsplice_prob + (1.0 - cmdlineopts.altsplice_prob) * (1.0 - support2);
+    dp_score_t unused_penalty2 = (dp_score_t)-LOG(unused_prob2);
+
+    /* add missing edges (GraphAlign.h:685-722); is_matched is indexed with SOURCE-graph indices
+     * although it is in merged indexing — kept as in the reference. */
+    for (int side = 0; side < 2; ++side) {
+        const Graph &g = side == 0 ? g1 : g2;
+        const std::vector<index_t> &inv = side == 0 ? inv_mapping1 : inv_mapping2;
+        const dp_score_t pen = side == 0 ? unused_penalty1 : unused_penalty2;
+        for (index_t to = 0; to < g.size(); ++to) {
+            for (Graph::PredIterator from = g.getPreds(to, 0, 0); from; ++from) {
+                index_t y = inv[*from];
+                index_t x = inv[to];
+                if (!from.isRepeat()) {
+                    if (result.is_matched[*from] && result.is_matched[to]) updateEdge(edges, y, x, (dp_score_t)(from.value() + pen));
+                    else if (result.is_matched[*from] || result.is_matched[to]) updateEdge(edges, y, x, (dp_score_t)(from.value() + pen / 2));
+                    else updateEdge(edges, y, x, from.value());
+                } else {
+                    updateEdge(repeats, y, x, from.repeatUnits());
+                }
+            }
+        }
+    }
+    result.graph = Graph(D, nodes, edges, repeats);
+    return result;
+}
+
+}  // namespace pgm

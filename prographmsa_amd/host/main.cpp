@@ -1,0 +1,152 @@
+// main.cpp — command-line driver mirroring the reference's main()/doAlign (src/main.cpp:32-483) for
+// the flags the hot path's configurations use.  TCLAP is not available, so a minimal parser accepts
+// the same spellings.  Built twice: `pgmsa` (HIP backend, the product) and, for tests only,
+// `oracle/_build/pgmsa_oracle` (CPU oracle backend).
+#include "pgm_host.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+using namespace pgm;
+
+static void usage() {
+    std::cerr << "USAGE: pgmsa [-f|--fasta] [-t|--tree <newick>] [-o <file>] [-T] [-I] [-a] [-m] [-M]\n"
+                 "             [--codon] [-c|--cs_profile <lib>] [-i <iters>] [-g rate] [-e prob] [-E prob]\n"
+                 "             [-s prob] [-A] [--dump_jobs <file>] [--stats] <fasta file>\n";
+}
+
+static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &seqs,
+                   std::map<std::string, std::string> &out_aligned, PhyTree *&out_tree, bool stats) {
+    // strip start/stop (main.cpp:332-353)
+    bool any_start = false, any_end = false;
+    std::map<std::string, bool> startStripped, endStripped;
+    std::map<std::string, sequence_t> seqs2;
+    for (const auto &kv : seqs) {
+        sequence_t seq = sequenceFromString(a, kv.second);
+        if (!cmdlineopts.noforcealign_flag) {
+            if (!seq.empty() && a.stripsStart(seq[0])) { seq = seq.substr(1); any_start = true; startStripped[kv.first] = true; }
+            else startStripped[kv.first] = false;
+            if (!seq.empty() && a.stripsEnd(seq[seq.size() - 1])) { seq = seq.substr(0, seq.size() - 1); any_end = true; endStripped[kv.first] = true; }
+            else endStripped[kv.first] = false;
+        }
+        seqs2[kv.first] = seq;
+    }
+    std::unique_ptr<ModelFactory> model_factory(ModelFactory::getDefault(a));
+    std::unique_ptr<CSProfile> csprofile;
+    if (!cmdlineopts.cs_file.empty()) csprofile.reset(new CSProfile(cmdlineopts.cs_file));
+
+    PhyTree *tree = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    if (!cmdlineopts.tree_file.empty()) {
+        std::ifstream ts(cmdlineopts.tree_file.c_str());
+        if (!ts) error("cannot open tree file %s", cmdlineopts.tree_file.c_str());
+        tree = parse_newick(ts);
+    } else {
+        tree = TreeNJ(a, seqs2, model_factory.get());
+    }
+    double t_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (cmdlineopts.iters != 0)
+        error("guide-tree re-estimation (-i > 0) needs DistanceFactoryPrealigned, which is outside this build's scope; use -i 0 or --tree");
+
+    ProgressiveAlignmentResult result;
+    t0 = std::chrono::steady_clock::now();
+    if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
+    double t_prog = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out_tree = tree;
+
+    // re-insert start/stop (main.cpp:459-482)
+    for (auto &kv : result.aligned_sequences) {
+        sequence_t aseq = kv.second;
+        if (any_start) aseq.insert(aseq.begin(), startStripped[kv.first] ? a.unknown() : a.gap());
+        if (any_end) aseq.insert(aseq.end(), endStripped[kv.first] ? a.unknown() : a.gap());
+        out_aligned[kv.first] = stringFromSequence(a, aseq, seqs.at(kv.first));
+    }
+    if (stats) {
+        Backend &be = default_backend();
+        fprintf(stderr,
+                "{\"backend\": \"%s\", \"tree_s\": %.6f, \"progressive_s\": %.6f, \"align_cells\": %llu, \"align_s\": %.6f, "
+                "\"nw_cells\": %llu, \"nw_s\": %.6f}\n",
+                be.name(), t_tree, t_prog, (unsigned long long)be.cells_aligned, be.seconds_align,
+                (unsigned long long)be.cells_nw, be.seconds_nw);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    try {
+        bool iters_set = false, stats = false, indel_set = false, edgehl_set = false, maxdist_set = false, cutdist_set = false;
+        std::string dump;
+        for (int i = 1; i < argc; ++i) {
+            std::string s = argv[i];
+            auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
+            if (s == "-f" || s == "--fasta") cmdlineopts.fasta_flag = true;
+            else if (s == "-t" || s == "--tree") cmdlineopts.tree_file = val();
+            else if (s == "-o" || s == "--output") cmdlineopts.output_file = val();
+            else if (s == "-T" || s == "--only_tree") cmdlineopts.onlytree_flag = true;
+            else if (s == "-I" || s == "--input_order") cmdlineopts.inputorder_flag = true;
+            else if (s == "-a" || s == "--nwdist") cmdlineopts.nwdist_flag = true;
+            else if (s == "-m" || s == "--mldist") cmdlineopts.mldist_flag = true;
+            else if (s == "-M" || s == "--mldist_gap") cmdlineopts.mldist_gap_flag = true;
+            else if (s == "-A" || s == "--no_force_align") cmdlineopts.noforcealign_flag = true;
+            else if (s == "--codon") cmdlineopts.codon_flag = true;
+            else if (s == "-c" || s == "--cs_profile") cmdlineopts.cs_file = val();
+            else if (s == "-i" || s == "--iterations") { cmdlineopts.iters = atoi(val().c_str()); iters_set = true; }
+            else if (s == "-g" || s == "--indel_rate") { cmdlineopts.indel_rate = atof(val().c_str()); indel_set = true; }
+            else if (s == "-e" || s == "--gap_ext") cmdlineopts.gapext_prob = atof(val().c_str());
+            else if (s == "-E" || s == "--end_indel_prob") cmdlineopts.end_indel_prob = atof(val().c_str());
+            else if (s == "-s" || s == "--altsplice_prob") cmdlineopts.altsplice_prob = atof(val().c_str());
+            else if (s == "-l" || s == "--edge_halflife") { cmdlineopts.edge_halflife = atof(val().c_str()); edgehl_set = true; }
+            else if (s == "-x" || s == "--cutoff_dist") { cmdlineopts.cutoff_dist = atof(val().c_str()); cutdist_set = true; }
+            else if (s == "-d" || s == "--min_dist") cmdlineopts.min_dist = atof(val().c_str());
+            else if (s == "-D" || s == "--max_dist") { cmdlineopts.max_dist = atof(val().c_str()); maxdist_set = true; }
+            else if (s == "-p" || s == "--min_pdist") cmdlineopts.min_pdist = atof(val().c_str());
+            else if (s == "-P" || s == "--max_pdist") cmdlineopts.max_pdist = atof(val().c_str());
+            else if (s == "--dump_jobs") dump = val();
+            else if (s == "--stats") stats = true;
+            else if (s == "-h" || s == "--help") { usage(); return 0; }
+            else if (!s.empty() && s[0] == '-') { std::cerr << "Command line error: unknown flag " << s << std::endl; return 1; }
+            else cmdlineopts.sequence_file = s;
+        }
+        if (cmdlineopts.sequence_file.empty()) { usage(); return 1; }
+        if (cmdlineopts.codon_flag) {  // main.cpp:225-241
+            if (!indel_set) cmdlineopts.indel_rate /= 2.6;
+            if (!edgehl_set) cmdlineopts.edge_halflife *= 2.6;
+            if (!maxdist_set) cmdlineopts.max_dist = 5.0;
+            if (!cutdist_set) cmdlineopts.cutoff_dist = 5.0;
+        }
+        // main.cpp:243-246; this build also cannot iterate (see doAlign), so -a/-T runs behave as `-i 0`
+        if (!iters_set && (!cmdlineopts.tree_file.empty() || cmdlineopts.onlytree_flag)) cmdlineopts.iters = 0;
+        if (!dump.empty()) set_job_dump(dump);
+
+        std::vector<std::string> input_order;
+        std::map<std::string, std::string> seqs = read_fasta(cmdlineopts.sequence_file, input_order);
+        std::ofstream custom_out;
+        std::ostream *out = &std::cout;
+        if (!cmdlineopts.output_file.empty()) {
+            custom_out.open(cmdlineopts.output_file.c_str());
+            if (!custom_out) error("error opening output file");
+            out = &custom_out;
+        }
+        std::map<std::string, std::string> aligned;
+        PhyTree *tree = nullptr;
+        Alphabet a(cmdlineopts.codon_flag ? ALPHA_CODON : ALPHA_AA);
+        doAlign(a, seqs, aligned, tree, stats);
+        if (!cmdlineopts.onlytree_flag) {
+            std::vector<std::string> order = input_order;
+            if (!cmdlineopts.inputorder_flag) order = get_tree_order(tree);
+            if (!cmdlineopts.fasta_flag) std::cerr << "note: Stockholm output is not built here; writing FASTA" << std::endl;
+            write_fasta(aligned, order, *out);
+        } else {
+            *out << tree->formatNewick() << std::endl;
+        }
+        delete tree;
+    } catch (std::exception &e) {
+        std::cerr << "ERROR:" << e.what() << std::endl;
+        return 2;
+    }
+    return 0;
+}

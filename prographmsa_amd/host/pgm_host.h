@@ -1,0 +1,333 @@
+// pgm_host.h — host-side C++ mirror of the reference's progressive-alignment call surface.
+//
+// Dependency-free C++17 (no Eigen, no TCLAP).  Names, argument meaning and error behaviour
+// follow acg-team/ProGraphMSA so that the scaffolding around the hot path reads like the
+// reference; the three hot functions themselves (alignGraphs, DistanceFactoryAlign::alignPair,
+// CSProfile::createProfile) are thin wrappers over the C ABI of include/pgm_hip.h.
+//
+// Reference files mirrored (all under /root/reference/src):
+//   Alphabet.{h,cpp}  Model.h  ModelFactory.{h,cpp}  ModelFactoryWag.cpp  ModelFactoryEcm.cpp
+//   Graph.h  SequenceGraph.h  CleanedGraph.h  GraphAlign.h  ProgressiveAlignment.{h,cpp}
+//   PhyTree.{h,cpp}  newick.cpp  Fasta.cpp  TreeNJ.{h,cpp}  DistanceFactory*.{h,cpp}
+//   CSProfile.{h,cpp}  main.{h,cpp}
+#ifndef PGM_HOST_H_
+#define PGM_HOST_H_
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pgm_hip.h"
+
+namespace pgm {
+
+typedef double score_t;      // main.h:31
+typedef float dp_score_t;    // main.h:32
+typedef uint32_t index_t;    // main.h:33
+typedef double distance_t;   // main.h:34
+
+// ---------------------------------------------------------------------------------------
+// cmdlineopts (main.h:37-82) with the defaults of main.cpp:37-169
+struct cmdlineopts_t {
+    int iters = 2;
+    bool fasta_flag = false, noforcealign_flag = false, nwdist_flag = false, onlytree_flag = false;
+    bool mldist_flag = false, mldist_gap_flag = false, codon_flag = false, inputorder_flag = false;
+    bool ancestral_flag = false;
+    double indel_rate = 0.0093359375;
+    double end_indel_prob = 0.12;
+    double gapext_prob = 0.6119140625;
+    double edge_halflife = 0.3;
+    double altsplice_prob = 0.328125;
+    double pseudo_count = 1000;
+    double cutoff_dist = 2.2;
+    double repeat_rate = 0.1;
+    double repeatext_prob = 0.3;
+    double max_dist = 2.2, min_dist = 0.05, max_pdist = 0.8, min_pdist = 0.05;
+    std::string output_file, sequence_file, tree_file, cs_file;
+};
+extern cmdlineopts_t cmdlineopts;
+
+// error() of debug.cpp:43-52 prints and abort()s; the mirror throws so that the C-level
+// callers (and tests) can observe it.  main() maps it to exit code 2 like main.cpp:315-319.
+struct pgm_exception : std::runtime_error {
+    explicit pgm_exception(const std::string &m) : std::runtime_error(m) {}
+};
+[[noreturn]] void error(const char *fmt, ...);
+
+// ---------------------------------------------------------------------------------------
+// Alphabets (Alphabet.h:37-115).  A symbol is stored as the reference stores it in `data`:
+// AA keeps the raw character, Codon keeps the codon index (61 = unknown, 62 = gap, -1 = invalid).
+enum AlphabetKind { ALPHA_AA = 0, ALPHA_CODON = 1 };
+struct Alphabet {
+    AlphabetKind kind;
+    int DIM;
+    explicit Alphabet(AlphabetKind k) : kind(k), DIM(k == ALPHA_AA ? 20 : 61) {}
+    int value(int8_t data) const;                  // AA::value / Codon::value
+    bool isValid(int8_t data) const { int v = value(data); return v >= 0 && v < DIM; }
+    int8_t gap() const;                            // ALPHABET::GAP
+    int8_t unknown() const;                        // ALPHABET::X
+    bool isGap(int8_t d) const { return d == gap(); }
+    char asChar(int8_t data) const;
+    std::string asString(int8_t data) const;
+    bool stripsStart(int8_t first) const;          // main.cpp:340
+    bool stripsEnd(int8_t last) const;             // main.cpp:348
+};
+typedef std::basic_string<int8_t> sequence_t;
+sequence_t sequenceFromString(const Alphabet &a, const std::string &str);             // Alphabet.h:118
+std::string stringFromSequence(const Alphabet &a, const sequence_t &seq);             // :136
+std::string stringFromSequence(const Alphabet &a, const sequence_t &seq, const std::string &orig);  // :148
+
+// ---------------------------------------------------------------------------------------
+// Model (Model.h:8-24); matrices are dim x dim column-major.
+struct Model {
+    int dim = 0;
+    std::vector<double> M, P, Q, pi;
+    double delta = 0, epsilon = 0;
+    distance_t distance = 0, divergence = 0;
+};
+
+// ModelFactory (ModelFactory.h:11-34) with the WAG (ModelFactoryWag.cpp) and ECM
+// (ModelFactoryEcm.cpp) rate matrices.  The eigen-decomposition uses the reversibility of the
+// models (symmetrised Jacobi) instead of Eigen's general EigenSolver; P(t) agrees to ~1e-15.
+class ModelFactory {
+public:
+    static ModelFactory *getDefault(const Alphabet &a);          // ModelFactory.cpp:11-36
+    Model getModel(distance_t distance) const;                   // ModelFactory.h:48-67
+    Model getModel(distance_t distance, distance_t gap_distance) const;  // :70-90
+    double getEpsilon(distance_t) const { return cmdlineopts.gapext_prob; }
+    double getDelta(distance_t distance) const;
+    int dim() const { return dim_; }
+    const std::vector<double> &Qmat() const { return Q_; }
+    const std::vector<double> &freqs() const { return freqs_; }
+
+private:
+    ModelFactory(int dim, const std::string &qmat_file);
+    static void parseDistance(distance_t distance, Model &model);  // ModelFactory.h:104-127
+    void fillP(Model &model) const;
+    int dim_;
+    std::vector<double> freqs_, Q_, V_, Vi_, sigma_;
+};
+
+// ---------------------------------------------------------------------------------------
+// Graph (Graph.h:20-502): profile matrix + two CSR matrices (edges float, repeats uint).
+class Graph {
+public:
+    typedef std::map<std::pair<index_t, index_t>, dp_score_t> EdgeMap;   // key (to,from)
+    typedef std::map<std::pair<index_t, index_t>, index_t> RepeatMap;
+
+    Graph() : Graph(20) {}
+    explicit Graph(int dim);                                                    // Graph.h:141-150
+    Graph(int dim, const std::vector<std::vector<double>> &nodes);              // :104-120
+    Graph(int dim, const std::vector<std::vector<double>> &nodes, const EdgeMap &edges,
+          const RepeatMap &repeats);                                            // :122-139
+
+    index_t size() const { return n_; }
+    int dim() const { return dim_; }
+    const double *col(index_t i) const { return &sites_[(size_t)dim_ * i]; }
+    const std::vector<double> &getSites() const { return sites_; }
+    pgm_graph flat() const;  // view for the C ABI (valid while *this is alive and unchanged)
+
+    // PredIterator (Graph.h:180-248)
+    class PredIterator {
+    public:
+        PredIterator(const Graph &g, index_t row, dp_score_t repeat_init, dp_score_t repeat_ext);
+        PredIterator &operator++() { if (i_ < iend_) ++i_; else ++j_; return *this; }
+        bool isRepeat() const { return !(i_ < iend_); }
+        index_t repeatUnits() const { return g_->r_units_[j_]; }
+        explicit operator bool() const { return i_ < iend_ || j_ < jend_; }
+        dp_score_t value() const;
+        dp_score_t rawValue() const { return g_->e_val_[i_]; }
+        index_t operator*() const { return i_ < iend_ ? g_->e_col_[i_] : g_->r_col_[j_]; }
+    private:
+        const Graph *g_;
+        int32_t i_, iend_, j_, jend_;
+        dp_score_t repeatInit_, repeatExt_;
+    };
+    PredIterator getPreds(index_t node, dp_score_t repeat_init, dp_score_t repeat_ext) const {
+        return PredIterator(*this, node, repeat_init, repeat_ext);
+    }
+
+protected:
+    void fillInitialEdges();                            // :35-46
+    void setEdgesFromMap(const EdgeMap &edge_map);      // :81-90
+    void setRepeatsFromMap(const RepeatMap &rep_map);   // :92-100
+    int dim_;
+    index_t n_;
+    std::vector<double> sites_;  // dim x n column-major
+    std::vector<int32_t> e_rowptr_;
+    std::vector<uint32_t> e_col_;
+    std::vector<float> e_val_;
+    std::vector<int32_t> r_rowptr_;
+    std::vector<uint32_t> r_col_;
+    std::vector<uint32_t> r_units_;
+    friend class CleanedGraph;
+};
+
+// SequenceGraph (SequenceGraph.h:101-121)
+Graph SequenceGraph(const Alphabet &a, const sequence_t &seq);
+Graph SequenceGraphFromProfile(int dim, index_t nnodes, const std::vector<double> &sites);  // :111-121
+
+// CleanedGraph (CleanedGraph.h:39-160)
+class CleanedGraph : public Graph {
+public:
+    explicit CleanedGraph(const Graph &original);
+    index_t getMapping(index_t i) const { return outmapping_[i]; }
+    void uncleanMapping(std::vector<index_t> &mapping) const;
+private:
+    std::vector<index_t> outmapping_;
+};
+
+// ---------------------------------------------------------------------------------------
+// GraphAlign.h
+struct AlignmentResult {   // GraphAlign.h:6-12
+    dp_score_t score = 0;
+    index_t n_tr_indels = 0;
+    std::vector<index_t> mapping1, mapping2;
+};
+struct AncestralResult {   // GraphAlign.h:14-20
+    Graph graph;
+    std::vector<index_t> mapping1, mapping2;
+    std::vector<bool> is_matched;
+};
+double averageAlignmentLength(const Graph &g);                                        // :82-96
+pgm_scores DynProgScores(const Graph &g1, const Graph &g2, const Model &model);       // :98-143
+
+// Backend = the C ABI entry points of include/pgm_hip.h behind a context.  The product binds
+// them to libpgm_hip.so (HIP kernels); tests bind the oracle.  There is no CPU fallback: when
+// the HIP library cannot create a context this throws.
+struct Backend {
+    virtual ~Backend() {}
+    virtual const char *name() const = 0;
+    virtual void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                                    const pgm_model *const *model, const pgm_scores *scores,
+                                    pgm_align_out *out) = 0;
+    virtual void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
+                                const int8_t *syms, const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
+                                const uint32_t *pj, int32_t *counts, uint32_t *gaps) = 0;
+    virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
+                                        const double *tau, const double *pi, const double *p_uniform, double *out,
+                                        const uint64_t *out_offs) = 0;
+    uint64_t cells_aligned = 0;   // Σ (n1-2)(n2-2)
+    uint64_t cells_nw = 0;        // Σ L1*L2
+    double seconds_align = 0, seconds_nw = 0;
+};
+Backend &default_backend();            // defined by exactly one backend_*.cpp linked into the program
+void set_job_dump(const std::string &path);  // if set, every alignGraphs job is appended to this file
+
+// alignGraphs (GraphAlign.h:200-534): one job; and the batched form the scheduler uses.
+AlignmentResult alignGraphs(const Graph &g1, const Graph &g2, const Model &model);
+std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1,
+                                              const std::vector<const Graph *> &g2,
+                                              const std::vector<const Model *> &model);
+// mergeGraphs (GraphAlign.h:550-727)
+AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
+                            const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
+                            double support1, double support2);
+
+// ---------------------------------------------------------------------------------------
+// PhyTree (PhyTree.h) + newick (newick.cpp)
+class PhyTree {
+public:
+    explicit PhyTree(std::string name = "") : parent_(nullptr), branch_length_(0), branch_support_(1), name_(std::move(name)) {}
+    ~PhyTree();
+    PhyTree(const PhyTree &) = delete;
+    PhyTree *copy() const;
+    void addChild(PhyTree *child, double branch_length = 0, double branch_support = 1);
+    void pluck();
+    PhyTree *pluckChild(index_t index);
+    index_t indexOf() const;
+    const std::string &getName() const { return name_; }
+    PhyTree *getParent() { return parent_; }
+    double getBranchLength() const { return branch_length_; }
+    double getBranchSupport() const { return branch_support_; }
+    PhyTree &operator[](int i) { return *children_[i]; }
+    const PhyTree &operator[](int i) const { return *children_[i]; }
+    index_t n_children() const { return (index_t)children_.size(); }
+    bool isLeaf() const { return children_.empty(); }
+    std::string formatNewick() const;
+private:
+    std::string formatNewickR() const;
+    std::vector<PhyTree *> children_;
+    PhyTree *parent_;
+    double branch_length_, branch_support_;
+    std::string name_;
+};
+PhyTree *midpointRoot(PhyTree *root);                      // PhyTree.cpp:60-116
+std::vector<std::string> get_tree_order(const PhyTree *tree);  // PhyTree.cpp:164-182
+PhyTree *parse_newick(std::istream &in);                   // newick.cpp:127-147
+
+// Fasta.cpp
+std::map<std::string, std::string> read_fasta(const std::string &file, std::vector<std::string> &order);
+void write_fasta(const std::map<std::string, std::string> &aln, const std::vector<std::string> &order, std::ostream &out);
+
+// ---------------------------------------------------------------------------------------
+// CSProfile (CSProfile.{h,cpp})
+class CSProfile {
+public:
+    explicit CSProfile(const std::string &filename);   // parser CSProfile.cpp:29-170
+    int nprof() const { return nprof_; }
+    int ncols() const { return ncols_; }
+    const std::vector<double> &lprofiles() const { return lprofiles_; }  // [k][col][21]
+    const std::vector<double> &centre() const { return centre_; }        // [k][20]
+    const std::vector<double> &priors() const { return priors_; }
+private:
+    int nprof_ = -1, ncols_ = -1;
+    std::vector<double> lprofiles_, centre_, priors_;
+};
+
+// ---------------------------------------------------------------------------------------
+// ProgressiveAlignment.{h,cpp}
+struct ProgressiveAlignmentResult {   // ProgressiveAlignment.h:27-37
+    std::map<std::string, sequence_t> aligned_sequences;
+    Graph graph;
+    score_t score = 0;
+    index_t n_tr_indels = 0;
+    bool is_csprofile = false;
+};
+// align_progressive_results (ProgressiveAlignment.h:413-476) for a whole guide-tree level at once.
+// progressive_alignment (ProgressiveAlignment.cpp:12-71): same post-order results as the reference's
+// recursion; internal nodes whose children are finished are aligned together in one batch.
+ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
+                                                 const PhyTree &tree, const CSProfile *csprofile,
+                                                 const ModelFactory &model_factory);
+
+// ---------------------------------------------------------------------------------------
+// Distances / guide tree
+struct DistanceMatrix {   // DistanceFactory.h:12-18
+    int dim;
+    std::vector<double> distances, variances;   // dim x dim
+    explicit DistanceMatrix(int d) : dim(d), distances((size_t)d * d, 0.0), variances((size_t)d * d, 0.0) {}
+    double &D(int i, int j) { return distances[(size_t)i * dim + j]; }
+    double &V(int i, int j) { return variances[(size_t)i * dim + j]; }
+};
+struct distvar_t { distance_t dist, var; };
+class DistanceFactoryML {   // DistanceFactoryML.h
+public:
+    DistanceFactoryML(const Alphabet &a, const ModelFactory *mf) : alphabet(a), model_factory(mf) {}
+    distvar_t computeDistance(const std::vector<int32_t> &counts, index_t gaps, double seqlen) const;  // :137-190
+protected:
+    distvar_t computeMLDist(const std::vector<int32_t> &counts, index_t gaps, double seqlen, double dist0, double var0) const;  // :66-135
+    Alphabet alphabet;
+    const ModelFactory *model_factory;
+};
+class DistanceFactoryAlign : public DistanceFactoryML {   // DistanceFactoryAlign.h
+public:
+    DistanceFactoryAlign(const Alphabet &a, const ModelFactory *mf);
+    DistanceMatrix computePwDistances(const std::map<std::string, sequence_t> &sequences,
+                                      const std::vector<std::string> &order);   // :29-56
+    const std::vector<int32_t> &scoring_matrix() const { return scoring_matrix_; }
+    int gap_open = -10, gap_extend = -2;
+private:
+    std::vector<int32_t> scoring_matrix_;   // (DIM+1)^2 column-major
+};
+PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist);   // TreeNJ.cpp:132-281 (no topology plan)
+PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf);  // TreeNJ.h:27-59, -a only
+
+std::string data_dir();   // directory holding wag.qmat etc.
+
+}  // namespace pgm
+#endif

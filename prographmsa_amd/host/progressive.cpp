@@ -1,0 +1,185 @@
+// progressive.cpp — progressive alignment driver (reference src/ProgressiveAlignment.{h,cpp}).
+//
+// The reference recurses strictly sequentially (ProgressiveAlignment.cpp:50-51).  The results of
+// sibling subtrees are independent, so this driver walks the tree level by level ("height" = longest
+// path to a leaf) and hands every ready internal node of a level to the backend in ONE batched
+// alignGraphs call; the per-node host work (CleanedGraph, mergeGraphs, extend_alignment) runs on a
+// few host threads.  The values produced per node are those of the reference's recursion.
+#include "pgm_host.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <thread>
+
+namespace pgm {
+
+// extend_alignment (ProgressiveAlignment.h:245-264)
+static void extend_alignment(const Alphabet &a, ProgressiveAlignmentResult &result, const std::vector<index_t> &mapping,
+                             const std::map<std::string, sequence_t> &aligned_sequences) {
+    for (const auto &kv : aligned_sequences) {
+        sequence_t extended(result.graph.size() - 2, a.unknown());
+        const sequence_t &original = kv.second;
+        index_t k = 0;
+        for (index_t j = 1; j < result.graph.size() - 1; ++j) {
+            if (mapping[j] != (index_t)-1) extended[j - 1] = original[k++];
+            else extended[j - 1] = a.gap();
+        }
+        result.aligned_sequences[kv.first] = extended;
+    }
+}
+
+static void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
+    nt = std::max(1u, std::min(nt, 16u));
+    nt = (unsigned)std::min<size_t>(nt, n);
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> errs(nt);
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            try { for (size_t i = t; i < n; i += nt) fn(i); }
+            catch (std::exception &e) { errs[t] = e.what(); }
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errs) if (!e.empty()) throw pgm_exception(e);
+}
+
+namespace {
+struct Node {
+    const PhyTree *tree;
+    int child[2] = {-1, -1};
+    int height = 0;
+    ProgressiveAlignmentResult res;
+};
+struct Pending {  // state of one align_progressive_results call between its two halves
+    Model model, model1, model2;
+    std::unique_ptr<CleanedGraph> cg1, cg2;
+};
+}  // namespace
+
+static int collect(const PhyTree &t, std::vector<Node> &nodes) {
+    if (!t.isLeaf() && t.n_children() != 2) error("only bifurcating trees allowed");
+    int c0 = -1, c1 = -1;
+    if (!t.isLeaf()) {
+        c0 = collect(t[0], nodes);
+        c1 = collect(t[1], nodes);
+    }
+    Node n;
+    n.tree = &t;
+    n.child[0] = c0;
+    n.child[1] = c1;
+    n.height = t.isLeaf() ? 0 : 1 + std::max(nodes[c0].height, nodes[c1].height);
+    nodes.push_back(std::move(n));
+    return (int)nodes.size() - 1;
+}
+
+ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
+                                                 const PhyTree &tree, const CSProfile *csprofile,
+                                                 const ModelFactory &model_factory) {
+    std::vector<Node> nodes;
+    int root = collect(tree, nodes);
+    int maxh = nodes[root].height;
+
+    // ---- leaves (ProgressiveAlignment.cpp:17-46) ----
+    std::vector<int> leaves;
+    for (size_t i = 0; i < nodes.size(); ++i)
+        if (nodes[i].tree->isLeaf()) leaves.push_back((int)i);
+    for (int li : leaves) {
+        Node &nd = nodes[li];
+        auto it = sequences.find(nd.tree->getName());
+        if (it == sequences.end()) error("unknown sequence name: %s", nd.tree->getName().c_str());
+        nd.res.aligned_sequences[it->first] = it->second;
+        nd.res.score = 0;
+        nd.res.n_tr_indels = 0;
+        nd.res.is_csprofile = false;
+        if (!csprofile) nd.res.graph = SequenceGraph(a, it->second);
+    }
+    if (csprofile) {
+        // SequenceGraph(seq, csprofile, model_factory.getModel(branch_length)) for every leaf in one
+        // createProfile batch (SequenceGraph.h:111-121, CSProfile.cpp:175-225).
+        if (a.kind != ALPHA_AA) error("context-specific profiles need the AA alphabet");
+        const uint32_t ns = (uint32_t)leaves.size();
+        std::vector<int8_t> syms;
+        std::vector<uint32_t> offs(ns + 1, 0);
+        std::vector<uint64_t> out_offs(ns + 1, 0);
+        std::vector<double> tau(ns), p_uniform((size_t)ns * 20), pi;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const Node &nd = nodes[leaves[s]];
+            const sequence_t &seq = sequences.at(nd.tree->getName());
+            for (int8_t c : seq) syms.push_back(a.isValid(c) ? (int8_t)a.value(c) : (int8_t)20);
+            offs[s + 1] = (uint32_t)syms.size();
+            out_offs[s + 1] = out_offs[s] + (uint64_t)20 * (seq.size() + 2);
+            Model m = model_factory.getModel(nd.tree->getBranchLength());
+            tau[s] = m.divergence / 0.8;
+            pi = m.pi;
+            for (int i = 0; i < 20; ++i) {  // model.P * Constant(1/20)
+                double acc = 0;
+                for (int j = 0; j < 20; ++j) acc += m.P[i + 20 * j] * (1.0 / 20);
+                p_uniform[(size_t)s * 20 + i] = acc;
+            }
+        }
+        std::vector<double> out(out_offs[ns]);
+        default_backend().csprofile_create_batch(*csprofile, ns, syms.data(), offs.data(), tau.data(), pi.data(),
+                                                 p_uniform.data(), out.data(), out_offs.data());
+        for (uint32_t s = 0; s < ns; ++s) {
+            Node &nd = nodes[leaves[s]];
+            index_t nn = (index_t)((out_offs[s + 1] - out_offs[s]) / 20);
+            std::vector<double> sites(out.begin() + out_offs[s], out.begin() + out_offs[s + 1]);
+            nd.res.graph = SequenceGraphFromProfile(20, nn, sites);
+            nd.res.is_csprofile = true;
+        }
+    }
+
+    // ---- internal nodes, one guide-tree level per batch (ProgressiveAlignment.h:413-476) ----
+    for (int h = 1; h <= maxh; ++h) {
+        std::vector<int> level;
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i].height == h) level.push_back((int)i);
+        const size_t L = level.size();
+        std::vector<Pending> pend(L);
+        parallel_for(L, [&](size_t k) {
+            Node &nd = nodes[level[k]];
+            const ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
+            double distance1 = (*nd.tree)[0].getBranchLength(), distance2 = (*nd.tree)[1].getBranchLength();
+            double gap_distance1 = distance1, gap_distance2 = distance2;
+            if (r1.is_csprofile) distance1 = 0;
+            if (r2.is_csprofile) distance2 = 0;
+            Pending &p = pend[k];
+            p.model = model_factory.getModel(distance1 + distance2, gap_distance1 + gap_distance2);
+            p.model1 = model_factory.getModel(distance1, gap_distance1);
+            p.model2 = model_factory.getModel(distance2, gap_distance2);
+            p.cg1.reset(new CleanedGraph(r1.graph));
+            p.cg2.reset(new CleanedGraph(r2.graph));
+        });
+        std::vector<const Graph *> g1(L), g2(L);
+        std::vector<const Model *> mm(L);
+        for (size_t k = 0; k < L; ++k) { g1[k] = pend[k].cg1.get(); g2[k] = pend[k].cg2.get(); mm[k] = &pend[k].model; }
+        std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm);
+        parallel_for(L, [&](size_t k) {
+            Node &nd = nodes[level[k]];
+            ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
+            Pending &p = pend[k];
+            ProgressiveAlignmentResult &result = nd.res;
+            result.score = ar[k].score;
+            result.is_csprofile = false;
+            result.n_tr_indels = ar[k].n_tr_indels + r1.n_tr_indels + r2.n_tr_indels;
+            p.cg1->uncleanMapping(ar[k].mapping1);
+            p.cg2->uncleanMapping(ar[k].mapping2);
+            AncestralResult anc = mergeGraphs(r1.graph, r2.graph, ar[k].mapping1, ar[k].mapping2, p.model1, p.model2,
+                                              (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
+            result.graph = anc.graph;
+            extend_alignment(a, result, anc.mapping1, r1.aligned_sequences);
+            extend_alignment(a, result, anc.mapping2, r2.aligned_sequences);
+            // children are no longer needed (the reference copies them by value and drops them)
+            r1 = ProgressiveAlignmentResult();
+            r2 = ProgressiveAlignmentResult();
+            p.cg1.reset();
+            p.cg2.reset();
+        });
+    }
+    return std::move(nodes[root].res);
+}
+
+}  // namespace pgm
