@@ -1,0 +1,423 @@
+// pgm_capi.hip — host side of the C ABI declared in include/pgm_hip.h (libpgm_hip.so).
+// Flattens the caller's graphs into HBM-resident job descriptors and launches the HIP kernels of
+// pgm_align_kernels.h / pgm_nw_kernels.h / pgm_csprofile_kernels.h.  No CPU fallback exists: every
+// entry point needs a working gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pgm_align_kernels.h"
+#include "pgm_nw_kernels.h"
+#include "pgm_csprofile_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &m) { g_err = m; return code; }
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(PGM_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+struct pgm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    float nw_ms = 0, cs_ms = 0;
+    // context-profile library resident in HBM
+    uint32_t csK = 0, csC = 0;
+    double *cs_lprofiles = nullptr, *cs_centre = nullptr, *cs_priors = nullptr;
+};
+
+// ---- arena: one host staging buffer mirrored by one device allocation ------------------------
+struct Arena {
+    std::vector<uint8_t> host;
+    size_t put(const void *src, size_t bytes, size_t align = 16) {
+        size_t off = (host.size() + align - 1) / align * align;
+        host.resize(off + bytes);
+        if (src && bytes) memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+    size_t reserve(size_t bytes, size_t align = 16) { return put(nullptr, bytes, align); }
+};
+struct DevLayout {  // sizes of device-only regions
+    size_t bytes = 0;
+    size_t take(size_t b, size_t align = 256) {
+        size_t off = (bytes + align - 1) / align * align;
+        bytes = off + b;
+        return off;
+    }
+};
+
+struct pgm_align_batch {
+    uint32_t njobs = 0;
+    uint64_t cells = 0;
+    uint32_t maxdim = 0, maxnb = 0;
+    std::vector<PgmJob> jobs;         // host copy of the descriptors (device pointers inside)
+    std::vector<uint32_t> order;      // launch order: largest job first
+    uint8_t *d_in = nullptr;          // uploaded inputs (arena image)
+    uint8_t *d_work = nullptr;        // prep outputs, brow, maps, results, scratch
+    uint8_t *d_cells = nullptr;       // DP storage
+    PgmJob *d_jobs = nullptr;
+    uint32_t *d_order = nullptr;
+    size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0;
+    std::vector<size_t> res_off, map1_off, map2_off;  // offsets inside d_work
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" {
+
+const char *pgm_last_error(void) { return g_err.c_str(); }
+
+int pgm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pgm_ctx_create(int device, pgm_ctx **out) {
+    if (!out) return fail(PGM_ERR_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(PGM_ERR_DEVICE, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    pgm_ctx *c = new pgm_ctx;
+    c->device = device;
+    HIPCHK(hipGetDeviceProperties(&c->prop, device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return PGM_OK;
+}
+
+void pgm_ctx_destroy(pgm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->cs_lprofiles) (void)hipFree(ctx->cs_lprofiles);
+    if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
+    if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count) {
+    if (!ctx) return fail(PGM_ERR_INVALID, "null ctx");
+    if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    return PGM_OK;
+}
+
+}  // extern "C"
+
+// ---- flattening of one graph side -------------------------------------------------------------
+namespace {
+struct SideOff {
+    size_t sites, cc, xp, xc, xv, kill, pp, pc, pv, pu;
+};
+
+static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
+    const uint32_t n = g->n;
+    if (n < 2 || !g->sites || !g->e_rowptr) return PGM_ERR_INVALID;
+    std::vector<float> cc(n, INFINITY), xv, pv;
+    std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
+    std::vector<uint32_t> xc, pc, pu;
+    std::vector<uint8_t> kill(n, 0);
+    for (uint32_t v = 0; v < n; ++v) {
+        const int32_t eb = g->e_rowptr[v], ee = g->e_rowptr[v + 1];
+        if (eb > ee || eb < 0) return PGM_ERR_INVALID;
+        for (int32_t e = eb; e < ee; ++e) {
+            const uint32_t from = g->e_col[e];
+            if (from >= v) return PGM_ERR_INVALID;  // edges must point to earlier nodes (Graph.h:43, GraphAlign.h:631-656)
+            const float c = g->e_val[e];
+            const float val = (c == 0) ? INFINITY : c + 10000.0f;  // PredIterator::value, Graph.h:223-231
+            pc.push_back(from); pv.push_back(val); pu.push_back(0u);
+            if (from + 1 == v && cc[v] == INFINITY && val != INFINITY) cc[v] = val;
+            else { xc.push_back(from); xv.push_back(val); }
+        }
+        if (g->r_rowptr) {
+            for (int32_t e = g->r_rowptr[v]; e < g->r_rowptr[v + 1]; ++e) {
+                const uint32_t from = g->r_col[e];
+                if (from >= v) return PGM_ERR_INVALID;
+                const uint32_t units = g->r_units[e];
+                const float val = (units == 0) ? INFINITY : sc.repeat_init + sc.repeat_ext * (float)(units - 1);  // Graph.h:232-238
+                pc.push_back(from); pv.push_back(val); pu.push_back(0x80000000u | units);
+                xc.push_back(from); xv.push_back(val);
+            }
+        }
+        xp[v + 1] = (int32_t)xc.size();
+        pp[v + 1] = (int32_t)pc.size();
+        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) kill[v] = 1;
+    }
+    // at least one element each so that pointers are valid
+    if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
+    if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
+    o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);
+    o.cc = A.put(cc.data(), 4 * cc.size());
+    o.xp = A.put(xp.data(), 4 * xp.size());
+    o.xc = A.put(xc.data(), 4 * xc.size());
+    o.xv = A.put(xv.data(), 4 * xv.size());
+    o.kill = A.put(kill.data(), kill.size());
+    o.pp = A.put(pp.data(), 4 * pp.size());
+    o.pc = A.put(pc.data(), 4 * pc.size());
+    o.pv = A.put(pv.data(), 4 * pv.size());
+    o.pu = A.put(pu.data(), 4 * pu.size());
+    return PGM_OK;
+}
+
+template <int DP, int NW, int R>
+static hipError_t launch_fill(const pgm_align_batch *b, hipStream_t s) {
+    constexpr int NQ = DP / 4 + 1;
+    const size_t lds = (size_t)NW * R * NQ * sizeof(float4) + (size_t)((b->maxnb + 3) / 4 * 4) * sizeof(int);
+    hipError_t e = hipFuncSetAttribute((const void *)pgm_fill_kernel<DP, NW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pgm_fill_kernel<DP, NW, R>), dim3(b->njobs), dim3(NW * 64), lds, s, b->d_jobs, b->d_order);
+    return hipGetLastError();
+}
+
+static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
+    hipStream_t s = ctx->stream;
+    hipError_t e;
+    if (timed && (e = hipEventRecord(b->ev[0], s)) != hipSuccess) return e;
+    const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim) * sizeof(float);
+    hipLaunchKernelGGL(pgm_prep_kernel, dim3(b->njobs, 2), dim3(256), prep_lds, s, b->d_jobs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
+    if (b->maxdim <= 20) e = launch_fill<20, 8, 128>(b, s);
+    else e = launch_fill<64, 4, 128>(b, s);
+    if (e != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(64), 0, s, b->d_jobs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
+    return hipSuccess;
+}
+}  // namespace
+
+extern "C" {
+
+int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                           const pgm_model *const *model, const pgm_scores *scores, pgm_align_batch **out) {
+    if (!ctx || !out || (njobs && (!g1 || !g2 || !model || !scores))) return fail(PGM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    pgm_align_batch *b = new pgm_align_batch;
+    b->njobs = njobs;
+    b->jobs.resize(njobs);
+    Arena A;
+    DevLayout W, C;
+    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, brow, map1, map2, ms, mp, res, cells; };
+    std::vector<Off> off(njobs);
+    b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
+    for (uint32_t i = 0; i < njobs; ++i) {
+        const pgm_graph *a = g1[i], *c = g2[i];
+        if (!a || !c || !model[i] || a->dim != c->dim || a->dim == 0 || a->dim > 64 || a->n < 2 || c->n < 2 || !model[i]->M || !model[i]->pi) {
+            delete b;
+            return fail(PGM_ERR_INVALID, "invalid job " + std::to_string(i));
+        }
+        PgmJob &J = b->jobs[i];
+        memset(&J, 0, sizeof J);
+        J.n1 = a->n; J.n2 = c->n; J.dim = a->dim;
+        J.dp = a->dim <= 20 ? 20 : 64;
+        J.nb = (a->n - 1 + 63) / 64;
+        J.ncol = c->n - 1;
+        J.tsteps = J.ncol + 63;
+        J.maxn = std::max(a->n, c->n);
+        J.sc = scores[i];
+        b->maxdim = std::max(b->maxdim, a->dim);
+        b->maxnb = std::max(b->maxnb, J.nb);
+        b->cells += (uint64_t)(a->n - 2) * (c->n - 2);
+        Off &o = off[i];
+        if (flatten_side(a, J.sc, A, o.s1) != PGM_OK || flatten_side(c, J.sc, A, o.s2) != PGM_OK) {
+            delete b;
+            return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
+        }
+        o.M = A.put(model[i]->M, sizeof(double) * a->dim * a->dim);
+        o.pi = A.put(model[i]->pi, sizeof(double) * a->dim);
+        o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
+        o.a1 = W.take(sizeof(float) * J.n1);
+        o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
+        o.aux2 = W.take(sizeof(float4) * J.n2);
+        o.brow = W.take(sizeof(float2) * (size_t)J.nb * J.ncol);
+        o.map1 = W.take(4 * (size_t)(J.n1 + J.n2));
+        o.map2 = W.take(4 * (size_t)(J.n1 + J.n2));
+        o.ms = W.take(4 * (size_t)J.maxn);
+        o.mp = W.take(4 * (size_t)J.maxn);
+        o.res = W.take(sizeof(PgmJob::Result));
+        o.cells = C.take(sizeof(float4) * (size_t)J.nb * J.tsteps * 64u, 1024);
+        b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
+    }
+    b->in_bytes = std::max<size_t>(A.host.size(), 16);
+    b->work_bytes = std::max<size_t>(W.bytes, 16);
+    b->cell_bytes = std::max<size_t>(C.bytes, 16);
+    hipError_t e;
+    if ((e = hipMalloc((void **)&b->d_in, b->in_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_work, b->work_bytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs))) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(e == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    for (uint32_t i = 0; i < njobs; ++i) {
+        PgmJob &J = b->jobs[i];
+        const Off &o = off[i];
+        uint8_t *in = b->d_in, *w = b->d_work;
+        J.sites1 = (const double *)(in + o.s1.sites); J.sites2 = (const double *)(in + o.s2.sites);
+        J.M = (const double *)(in + o.M); J.pi = (const double *)(in + o.pi);
+        J.cc1 = (const float *)(in + o.s1.cc); J.cc2 = (const float *)(in + o.s2.cc);
+        J.xp1 = (const int32_t *)(in + o.s1.xp); J.xp2 = (const int32_t *)(in + o.s2.xp);
+        J.xc1 = (const uint32_t *)(in + o.s1.xc); J.xc2 = (const uint32_t *)(in + o.s2.xc);
+        J.xv1 = (const float *)(in + o.s1.xv); J.xv2 = (const float *)(in + o.s2.xv);
+        J.kill1 = in + o.s1.kill; J.kill2 = in + o.s2.kill;
+        J.pp1 = (const int32_t *)(in + o.s1.pp); J.pp2 = (const int32_t *)(in + o.s2.pp);
+        J.pc1 = (const uint32_t *)(in + o.s1.pc); J.pc2 = (const uint32_t *)(in + o.s2.pc);
+        J.pv1 = (const float *)(in + o.s1.pv); J.pv2 = (const float *)(in + o.s2.pv);
+        J.pu1 = (const uint32_t *)(in + o.s1.pu); J.pu2 = (const uint32_t *)(in + o.s2.pu);
+        J.g1f = (float *)(w + o.g1f); J.a1 = (float *)(w + o.a1);
+        J.t2 = (float *)(w + o.t2); J.aux2 = (float4 *)(w + o.aux2);
+        J.brow = (float2 *)(w + o.brow);
+        J.map1 = (uint32_t *)(w + o.map1); J.map2 = (uint32_t *)(w + o.map2);
+        J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
+        J.result = (PgmJob::Result *)(w + o.res);
+        J.cells = (float4 *)(b->d_cells + o.cells);
+    }
+    b->order.resize(njobs);
+    std::iota(b->order.begin(), b->order.end(), 0u);
+    std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) {
+        return (uint64_t)b->jobs[x].n1 * b->jobs[x].n2 > (uint64_t)b->jobs[y].n1 * b->jobs[y].n2;
+    });
+    if ((e = hipMemcpyAsync(b->d_in, A.host.data(), A.host.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
+    }
+    for (int k = 0; k < 4; ++k) (void)hipEventCreate(&b->ev[k]);
+    *out = b;
+    return PGM_OK;
+}
+
+int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b) {
+    if (!ctx || !b) return fail(PGM_ERR_INVALID, "null argument");
+    if (b->njobs == 0) return PGM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(launch_all(ctx, b, false));
+    return PGM_OK;
+}
+
+int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep, float *ms_fill, float *ms_traceback) {
+    if (!ctx || !b || reps <= 0) return fail(PGM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    double acc[3] = {0, 0, 0};
+    for (int r = 0; r < reps && b->njobs; ++r) {
+        HIPCHK(launch_all(ctx, b, true));
+        HIPCHK(hipEventSynchronize(b->ev[3]));
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
+            acc[k] += ms;
+        }
+    }
+    if (ms_prep) *ms_prep = (float)(acc[0] / reps);
+    if (ms_fill) *ms_fill = (float)(acc[1] / reps);
+    if (ms_traceback) *ms_traceback = (float)(acc[2] / reps);
+    return PGM_OK;
+}
+
+int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) {
+    if (!ctx || !b || (b->njobs && !out)) return fail(PGM_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (b->njobs == 0) return PGM_OK;
+    // results + maps live in d_work; copy the whole map/result region of each job
+    int rc = PGM_OK;
+    std::vector<PgmJob::Result> res(b->njobs);
+    for (uint32_t i = 0; i < b->njobs; ++i)
+        HIPCHK(hipMemcpyAsync(&res[i], b->d_work + b->res_off[i], sizeof(PgmJob::Result), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < b->njobs; ++i) {
+        out[i].score = res[i].score;
+        out[i].n_tr_indels = res[i].n_tr_indels;
+        out[i].len = res[i].len;
+        out[i].status = res[i].status;
+        if (res[i].status != PGM_OK) rc = res[i].status;
+        if (!out[i].map1 || !out[i].map2) return fail(PGM_ERR_INVALID, "null mapping buffer");
+        HIPCHK(hipMemcpyAsync(out[i].map1, b->d_work + b->map1_off[i], 4 * (size_t)res[i].len, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(out[i].map2, b->d_work + b->map2_off[i], 4 * (size_t)res[i].len, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rc != PGM_OK) g_err = "backtracking failed";
+    return rc;
+}
+
+void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < 4; ++k)
+        if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
+    if (b->d_in) (void)hipFree(b->d_in);
+    if (b->d_work) (void)hipFree(b->d_work);
+    if (b->d_cells) (void)hipFree(b->d_cells);
+    if (b->d_jobs) (void)hipFree(b->d_jobs);
+    if (b->d_order) (void)hipFree(b->d_order);
+    delete b;
+}
+
+uint64_t pgm_align_batch_cells(const pgm_align_batch *b) { return b ? b->cells : 0; }
+
+int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                           const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) {
+    pgm_align_batch *b = nullptr;
+    int rc = pgm_align_batch_create(ctx, njobs, g1, g2, model, scores, &b);
+    if (rc != PGM_OK) return rc;
+    rc = pgm_align_batch_run(ctx, b);
+    if (rc == PGM_OK) rc = pgm_align_batch_fetch(ctx, b, out);
+    pgm_align_batch_destroy(ctx, b);
+    return rc;
+}
+
+int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job, float *M, float *X, float *Y, float *W, float *S) {
+    if (!ctx || !b || job >= b->njobs) return fail(PGM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const PgmJob &J = b->jobs[job];
+    const size_t N = (size_t)J.n1 * J.n2;
+    if (M || X || Y || W) {
+        const size_t ncell = (size_t)J.nb * J.tsteps * 64u;
+        std::vector<float4> cells(ncell);
+        HIPCHK(hipMemcpy(cells.data(), J.cells, ncell * sizeof(float4), hipMemcpyDeviceToHost));
+        float *dst[4] = {M, X, Y, W};
+        for (int k = 0; k < 4; ++k)
+            if (dst[k]) std::fill(dst[k], dst[k] + N, -INFINITY);
+        for (uint32_t y = 0; y + 1 < J.n1; ++y)
+            for (uint32_t x = 0; x < J.ncol; ++x) {
+                const uint32_t bb = y >> 6, l = y & 63u;
+                const float4 c = cells[((size_t)bb * J.tsteps + (x + l)) * 64u + l];
+                const size_t i = (size_t)y + (size_t)J.n1 * x;
+                if (M) M[i] = c.x;
+                if (X) X[i] = c.y;
+                if (Y) Y[i] = c.z;
+                if (W) W[i] = c.w;
+            }
+    }
+    if (S) {
+        float *dS = nullptr;
+        HIPCHK(hipMalloc((void **)&dS, N * sizeof(float)));
+        hipLaunchKernelGGL(pgm_emission_kernel, dim3(512), dim3(256), 0, ctx->stream, b->d_jobs, job, dS);
+        hipError_t e = hipMemcpyAsync(S, dS, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(dS);
+        if (e != hipSuccess) return fail(PGM_ERR_DEVICE, hipGetErrorString(e));
+    }
+    return PGM_OK;
+}
+
+}  // extern "C"
+
+#include "pgm_nw_capi.inc"
+#include "pgm_csprofile_capi.inc"

@@ -1,0 +1,151 @@
+// pgm_nw_kernels.h — all-pairs integer Gotoh alignment + traceback counts
+// (reference src/DistanceFactoryAlign.h:59-127 alignPair).  Exact int32 arithmetic.
+//
+// One wavefront per sequence pair, pairs pulled from a device-side work queue (atomic counter), so
+// the kernel is a persistent grid sized to the chip.  The wavefront sweeps seq2 (rows) in bands of 64
+// (lane = row) along seq1 (columns) with the same one-column-per-lane skew as the graph DP: the
+// (y-1,x-1), (y-1,x) neighbours arrive by one DPP shift, (y,x-1) is the lane's own register, the symbol
+// of seq1 travels down the lanes systolically.  The reference keeps three int32 matrices (12 B/cell) for
+// its traceback; the traceback only ever asks "which of diag / X / Y equals W at this cell" (priority
+// diag > X > Y, DistanceFactoryAlign.h:100-123), so 2 direction bits per cell are stored instead,
+// 16 steps per 32-bit word, and the last row of a band is kept in a per-wave scratch row for the next band.
+#ifndef PGM_NW_KERNELS_H_
+#define PGM_NW_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PgmNwArgs {
+    uint32_t dim;            // alphabet size D; scoring matrix is (D+1)^2 column-major
+    int32_t gap_open, gap_extend;
+    uint32_t npairs;
+    const int32_t *score;
+    const int8_t *syms;
+    const uint32_t *offs;
+    const uint32_t *pi, *pj;
+    const uint32_t *order;   // pair processing order (longest first)
+    int32_t *counts;         // npairs x D x D, zero-initialised
+    uint32_t *gaps;          // npairs
+    uint32_t *queue;         // work counter, zero-initialised
+    uint32_t *dirs;          // per wave slot: dir_words_per_slot uint32
+    int2 *brow;              // per wave slot: brow_per_slot int2
+    size_t dir_words_per_slot;
+    size_t brow_per_slot;
+    int32_t *status;         // set to PGM_ERR_BACKTRACK if a traceback finds no matching source
+};
+
+__device__ __forceinline__ int pgm_dpp_shr1_i(int src, int lane0_value) {
+    return __builtin_amdgcn_update_dpp(lane0_value, src, 0x138, 0xf, 0xf, false);
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
+    extern __shared__ int nw_score[];  // (D+1)^2
+    const int sd = (int)A.dim + 1;
+    for (int i = threadIdx.x; i < sd * sd; i += WAVES * 64) nw_score[i] = A.score[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const size_t slot = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    uint32_t *dirs = A.dirs + slot * A.dir_words_per_slot;
+    int2 *brow = A.brow + slot * A.brow_per_slot;
+    const int go = A.gap_open, ge = A.gap_extend;
+    const int MINF = -10000;
+
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(A.queue, 1u);
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        if (q >= A.npairs) break;
+        const uint32_t p = A.order[q];
+        const uint32_t i1 = A.pi[p], i2 = A.pj[p];
+        const int8_t *s1 = A.syms + A.offs[i1];
+        const int8_t *s2 = A.syms + A.offs[i2];
+        const int L1 = (int)(A.offs[i1 + 1] - A.offs[i1]);  // columns
+        const int L2 = (int)(A.offs[i2 + 1] - A.offs[i2]);  // rows
+        const int nb = (L2 + 63) / 64;
+        const int tsteps = L1 + 63;
+        const int twords = (tsteps + 15) / 16;
+
+        for (int b = 0; b < nb; ++b) {
+            const int y = 64 * b + lane + 1;  // 1..L2
+            const bool rowvalid = y <= L2;
+            const int sy = rowvalid ? (int)s2[y - 1] : 0;
+            int W_left = go + (y - 1) * ge;           // W(y,0) = Y(y,0)
+            int X_left = MINF;                        // X(y,0)
+            int W_diag = (y == 1) ? 0 : go + (y - 2) * ge;  // W(y-1,0)
+            int W_o = MINF, Y_o = MINF, sx_o = 0;
+            uint32_t word = 0;
+            for (int t0 = 0; t0 < tsteps; t0 += 64) {
+                // block prefetch for lane 0: seq1 symbols and the row above (columns t0+1 .. t0+64)
+                const int xc = t0 + lane + 1;
+                int pf_s = 0, pf_w = MINF, pf_y = MINF;
+                if (xc <= L1) {
+                    pf_s = (int)s1[xc - 1];
+                    if (b == 0) { pf_w = go + (xc - 1) * ge; pf_y = MINF; }
+                    else { const int2 v = brow[xc]; pf_w = v.x; pf_y = v.y; }
+                }
+                const int tend = min(64, tsteps - t0);
+                for (int i = 0; i < tend; ++i) {
+                    const int t = t0 + i;
+                    const int x = t - lane + 1;  // 1..L1
+                    const bool active = rowvalid && x >= 1 && x <= L1;
+                    const int sx = pgm_dpp_shr1_i(sx_o, __builtin_amdgcn_readlane(pf_s, i));
+                    const int W_up = pgm_dpp_shr1_i(W_o, __builtin_amdgcn_readlane(pf_w, i));
+                    const int Y_up = pgm_dpp_shr1_i(Y_o, __builtin_amdgcn_readlane(pf_y, i));
+                    const int sidx = sy + sd * sx;  // scoring_matrix(s2(y), s1(x))
+                    const int dc = W_diag + nw_score[active ? sidx : 0];
+                    const int Xv = max(X_left + ge, W_left + go);
+                    const int Yv = max(Y_up + ge, W_up + go);
+                    const int xy = max(Xv, Yv);
+                    const int Wv = max(xy, dc);
+                    const uint32_t dir = (dc >= xy) ? 0u : (Xv >= Yv ? 1u : 2u);
+                    word |= dir << ((t & 15) * 2);
+                    if ((t & 15) == 15 || t == tsteps - 1) {
+                        dirs[((size_t)b * twords + (t >> 4)) * 64 + lane] = word;
+                        word = 0;
+                    }
+                    if (active) {
+                        W_left = Wv;
+                        X_left = Xv;
+                        if (lane == 63 && b + 1 < nb) brow[x] = make_int2(Wv, Yv);
+                    }
+                    if (x >= 1) W_diag = W_up;  // keep W(y-1,0) until the lane reaches column 1
+                    W_o = active ? Wv : MINF;
+                    Y_o = active ? Yv : MINF;
+                    sx_o = sx;
+                }
+            }
+        }
+        // traceback + counts (DistanceFactoryAlign.h:93-124), lane 0
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t gaps = 0;
+            bool open1 = false, open2 = false;
+            int32_t *cnt = A.counts + (size_t)p * A.dim * A.dim;
+            int y = L2, x = L1;
+            while (y != 0 && x != 0) {
+                const int bb = (y - 1) >> 6, l = (y - 1) & 63;
+                const int t = (x - 1) + l;
+                const uint32_t w = dirs[((size_t)bb * twords + (t >> 4)) * 64 + l];
+                const uint32_t dir = (w >> ((t & 15) * 2)) & 3u;
+                if (dir == 0) {
+                    const int a = s1[x - 1], c = s2[y - 1];
+                    if (a < (int)A.dim && c < (int)A.dim) atomicAdd(&cnt[a + (int)A.dim * c], 1);
+                    open1 = false; open2 = false;
+                    --x; --y;
+                } else if (dir == 1) {
+                    if (!open1) ++gaps;
+                    open1 = true; open2 = false;
+                    --x;
+                } else {
+                    if (!open2) ++gaps;
+                    open1 = false; open2 = true;
+                    --y;
+                }
+            }
+            A.gaps[p] = gaps;
+        }
+    }
+}
+
+#endif
