@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — DP cell-updates/s of the alignGraphs hot path on the BASELINE workload (256 seqs x 1000 aa, WAG).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (config.workload): the 255 graph-vs-graph alignGraphs jobs of one progressive pass over the synthetic
+256 x 1000 aa family (tests/gen.py seed 3, guide tree tests/golden/c3.tree, --mldist), 2.71e8 DP cells, exactly the
+jobs the product driver issues (captured with `pgmsa --dump_jobs` on this GPU during untimed set-up).
+One "step" = one pass of the hot path over that batch with the inputs resident in HBM: prep (float casts,
+T = M^T g2) + fill (emission + DP) + traceback kernels, then the result/mapping copy back to the host.
+Multi-GPU: one process per GPU, every rank runs the same workload on its own device (independent jobs, no collective
+on the data path; weak scaling); torch.distributed is used only for the barrier and the max-over-ranks clock.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nseq", type=int, default=256, help="debug: smaller family (changes the workload; not the headline)")
+    ap.add_argument("--len", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import gen
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+
+    ctx = pg.Context(local_rank)
+    devname, cus = ctx.device_info()
+
+    # ---- untimed set-up: produce the jobs with the product driver on this GPU --------------------
+    tmp = tempfile.mkdtemp(prefix="pgm_bench_r%d_" % rank)
+    fa = os.path.join(tmp, "fam.fa")
+    headline = (args.nseq == 256 and args.len == 1000)
+    with open(fa, "w") as f:
+        f.write(gen.fasta(gen.gen(args.nseq, args.len, 3)))
+    env = dict(os.environ, PGM_DEVICE=str(local_rank))
+    dump = os.path.join(tmp, "jobs.bin")
+    if headline:
+        tree_args = ["-t", os.path.join(ROOT, "tests", "golden", "c3.tree")]
+    else:   # debug sizes: NW guide tree from the GPU all-pairs stage
+        tr = subprocess.run([pg.PGMSA_PATH, "-a", "-m", "-T", "-i", "0", fa], capture_output=True, text=True, env=env, check=True).stdout
+        with open(os.path.join(tmp, "t.tree"), "w") as f:
+            f.write(tr)
+        tree_args = ["-t", os.path.join(tmp, "t.tree")]
+    t0 = time.time()
+    r = subprocess.run([pg.PGMSA_PATH, "--fasta", "-m"] + tree_args + ["--dump_jobs", dump, "--stats", "-o", os.path.join(tmp, "out.fa"), fa],
+                       capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        raise SystemExit("pgmsa failed: " + r.stderr)
+    e2e_wall = time.time() - t0
+    stats = json.loads(r.stderr.strip().splitlines()[-1])
+    jobs = J.load_jobs(dump)
+    os.remove(dump)
+    batch = J.Batch(ctx, jobs)
+    cells = batch.cells
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+        batch.fetch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+        batch.fetch()
+    barrier()
+    dt = time.perf_counter() - t0
+    total_cells = float(cells) * args.steps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([total_cells], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        dt, total_cells = float(t.item()), float(c.item())
+
+    # ---- roofline of the dominant kernel (fill), HIP events on the library's stream ---------------
+    ms_prep, ms_fill, ms_tb = batch.time(5)
+    alg_bytes = 16.0 * cells            # one float4 {M,X,Y,W} store per cell, S fused
+    achieved = alg_bytes / (ms_fill * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "ms": {"prep": round(ms_prep, 4), "fill": round(ms_fill, 4), "traceback": round(ms_tb, 4)},
+                "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "DP cell-updates/sec (GCUPS) + wall-clock on 256 seqs × 1000 aa, WAG",
+            "value": round(total_cells / dt / 1e9, 4), "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d seqs x %d aa, WAG, --mldist: the %d alignGraphs jobs of one progressive pass "
+                                   "(%.3e DP cells) per GPU, inputs resident in HBM" % (args.nseq, args.len, len(jobs), cells),
+                       "headline": headline, "device": devname, "cus": cus, "jobs": len(jobs), "cells_per_step": cells},
+            "roofline": roofline,
+            "end_to_end": {"pgmsa_wall_s": round(e2e_wall, 3), "progressive_s": stats["progressive_s"],
+                           "align_call_s": stats["align_s"], "note": "untimed set-up run of the product driver incl. host merges, H2D/D2H and hipMalloc"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib   # test-only CPU restatement, used here solely as the reported CPU baseline
+            sample = jobs[::2]
+            tc = time.perf_counter()
+            for j in sample:
+                oracle_lib.align_graphs(j)
+            cdt = time.perf_counter() - tc
+            ccells = sum(j.cells for j in sample)
+            out["cpu_baseline"] = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": 1, "kind": "port",
+                                   "sample": "every 2nd job of the same batch (%d jobs, %.3e cells, %.1f s), oracle/pgm_oracle.c -O2, 1 thread"
+                                             % (len(sample), ccells, cdt)}
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,10 +64,12 @@ struct pgm_align_batch {
     uint8_t *d_in = nullptr;          // uploaded inputs (arena image)
     uint8_t *d_work = nullptr;        // prep outputs, brow, maps, results, scratch
     uint8_t *d_cells = nullptr;       // DP storage
+    uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
+    std::vector<uint8_t> h_out;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
-    size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0;
-    std::vector<size_t> res_off, map1_off, map2_off;  // offsets inside d_work
+    size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0, out_bytes = 0;
+    std::vector<size_t> res_off, map1_off, map2_off;  // offsets inside d_out
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -210,7 +212,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->njobs = njobs;
     b->jobs.resize(njobs);
     Arena A;
-    DevLayout W, C;
+    DevLayout W, C, O;
     struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, brow, map1, map2, ms, mp, res, cells; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
@@ -244,20 +246,21 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
         o.aux2 = W.take(sizeof(float4) * J.n2);
         o.brow = W.take(sizeof(float2) * (size_t)J.nb * J.ncol);
-        o.map1 = W.take(4 * (size_t)(J.n1 + J.n2));
-        o.map2 = W.take(4 * (size_t)(J.n1 + J.n2));
+        o.map1 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
+        o.map2 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.ms = W.take(4 * (size_t)J.maxn);
         o.mp = W.take(4 * (size_t)J.maxn);
-        o.res = W.take(sizeof(PgmJob::Result));
+        o.res = O.take(sizeof(PgmJob::Result), 16);
         o.cells = C.take(sizeof(float4) * (size_t)J.nb * J.tsteps * 64u, 1024);
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
     b->in_bytes = std::max<size_t>(A.host.size(), 16);
     b->work_bytes = std::max<size_t>(W.bytes, 16);
     b->cell_bytes = std::max<size_t>(C.bytes, 16);
+    b->out_bytes = std::max<size_t>(O.bytes, 16);
     hipError_t e;
     if ((e = hipMalloc((void **)&b->d_in, b->in_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_work, b->work_bytes)) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_out, b->out_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(e == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -265,7 +268,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     for (uint32_t i = 0; i < njobs; ++i) {
         PgmJob &J = b->jobs[i];
         const Off &o = off[i];
-        uint8_t *in = b->d_in, *w = b->d_work;
+        uint8_t *in = b->d_in, *w = b->d_work, *ob = b->d_out;
         J.sites1 = (const double *)(in + o.s1.sites); J.sites2 = (const double *)(in + o.s2.sites);
         J.M = (const double *)(in + o.M); J.pi = (const double *)(in + o.pi);
         J.cc1 = (const float *)(in + o.s1.cc); J.cc2 = (const float *)(in + o.s2.cc);
@@ -280,9 +283,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.g1f = (float *)(w + o.g1f); J.a1 = (float *)(w + o.a1);
         J.t2 = (float *)(w + o.t2); J.aux2 = (float4 *)(w + o.aux2);
         J.brow = (float2 *)(w + o.brow);
-        J.map1 = (uint32_t *)(w + o.map1); J.map2 = (uint32_t *)(w + o.map2);
+        J.map1 = (uint32_t *)(ob + o.map1); J.map2 = (uint32_t *)(ob + o.map2);
         J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
-        J.result = (PgmJob::Result *)(w + o.res);
+        J.result = (PgmJob::Result *)(ob + o.res);
         J.cells = (float4 *)(b->d_cells + o.cells);
     }
     b->order.resize(njobs);
@@ -334,23 +337,24 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (b->njobs == 0) return PGM_OK;
-    // results + maps live in d_work; copy the whole map/result region of each job
+    // results + mappings live in one contiguous device region: a single D2H copy, then scatter
     int rc = PGM_OK;
-    std::vector<PgmJob::Result> res(b->njobs);
-    for (uint32_t i = 0; i < b->njobs; ++i)
-        HIPCHK(hipMemcpyAsync(&res[i], b->d_work + b->res_off[i], sizeof(PgmJob::Result), hipMemcpyDeviceToHost, ctx->stream));
+    b->h_out.resize(b->out_bytes);
+    HIPCHK(hipMemcpyAsync(b->h_out.data(), b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (uint32_t i = 0; i < b->njobs; ++i) {
-        out[i].score = res[i].score;
-        out[i].n_tr_indels = res[i].n_tr_indels;
-        out[i].len = res[i].len;
-        out[i].status = res[i].status;
-        if (res[i].status != PGM_OK) rc = res[i].status;
+        PgmJob::Result res;
+        memcpy(&res, b->h_out.data() + b->res_off[i], sizeof res);
+        out[i].score = res.score;
+        out[i].n_tr_indels = res.n_tr_indels;
+        out[i].len = res.len;
+        out[i].status = res.status;
+        if (res.status != PGM_OK) rc = res.status;
         if (!out[i].map1 || !out[i].map2) return fail(PGM_ERR_INVALID, "null mapping buffer");
-        HIPCHK(hipMemcpyAsync(out[i].map1, b->d_work + b->map1_off[i], 4 * (size_t)res[i].len, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(out[i].map2, b->d_work + b->map2_off[i], 4 * (size_t)res[i].len, hipMemcpyDeviceToHost, ctx->stream));
+        if (res.len > b->jobs[i].n1 + b->jobs[i].n2) return fail(PGM_ERR_DEVICE, "corrupt result length");
+        memcpy(out[i].map1, b->h_out.data() + b->map1_off[i], 4 * (size_t)res.len);
+        memcpy(out[i].map2, b->h_out.data() + b->map2_off[i], 4 * (size_t)res.len);
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     if (rc != PGM_OK) g_err = "backtracking failed";
     return rc;
 }
@@ -363,6 +367,7 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (b->d_in) (void)hipFree(b->d_in);
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_cells) (void)hipFree(b->d_cells);
+    if (b->d_out) (void)hipFree(b->d_out);
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_order) (void)hipFree(b->d_order);
     delete b;

@@ -52,16 +52,23 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
     const int MINF = -10000;
 
     for (;;) {
-        uint32_t q = 0;
-        if (lane == 0) q = atomicAdd(A.queue, 1u);
+        // every lane takes part in the dequeue (lane 0 adds 1, the others 0): a lane-0-only branch in front of
+        // the readfirstlane was jump-threaded across the loop back-edge by hipcc (ROCm 7.2), which let lanes 1..63
+        // re-enter the loop body without lane 0 and spin forever
+        uint32_t q = atomicAdd(A.queue, lane == 0 ? 1u : 0u);
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
         if (q >= A.npairs) break;
-        const uint32_t p = A.order[q];
-        const uint32_t i1 = A.pi[p], i2 = A.pj[p];
-        const int8_t *s1 = A.syms + A.offs[i1];
-        const int8_t *s2 = A.syms + A.offs[i2];
-        const int L1 = (int)(A.offs[i1 + 1] - A.offs[i1]);  // columns
-        const int L2 = (int)(A.offs[i2 + 1] - A.offs[i2]);  // rows
+        // everything derived from the queue index is wave-uniform; say so explicitly so that the band and
+        // step loops below stay scalar loops (the loads themselves go through the vector path)
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.order[q]);
+        const uint32_t i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.pi[p]);
+        const uint32_t i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.pj[p]);
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.offs[i1]);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.offs[i2]);
+        const int8_t *s1 = A.syms + o1;
+        const int8_t *s2 = A.syms + o2;
+        const int L1 = __builtin_amdgcn_readfirstlane((int)(A.offs[i1 + 1] - o1));  // columns
+        const int L2 = __builtin_amdgcn_readfirstlane((int)(A.offs[i2 + 1] - o2));  // rows
         const int nb = (L2 + 63) / 64;
         const int tsteps = L1 + 63;
         const int twords = (tsteps + 15) / 16;
@@ -116,9 +123,10 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                 }
             }
         }
-        // traceback + counts (DistanceFactoryAlign.h:93-124), lane 0
-        if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // traceback + counts (DistanceFactoryAlign.h:93-124).  The walk is executed by the whole wavefront in
+        // lock-step (every lane reads the same direction word, so control flow stays uniform); only lane 0
+        // commits the side effects.
+        {
             uint32_t gaps = 0;
             bool open1 = false, open2 = false;
             int32_t *cnt = A.counts + (size_t)p * A.dim * A.dim;
@@ -126,11 +134,12 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
             while (y != 0 && x != 0) {
                 const int bb = (y - 1) >> 6, l = (y - 1) & 63;
                 const int t = (x - 1) + l;
-                const uint32_t w = dirs[((size_t)bb * twords + (t >> 4)) * 64 + l];
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)dirs[((size_t)bb * twords + (t >> 4)) * 64 + l]);
                 const uint32_t dir = (w >> ((t & 15) * 2)) & 3u;
                 if (dir == 0) {
-                    const int a = s1[x - 1], c = s2[y - 1];
-                    if (a < (int)A.dim && c < (int)A.dim) atomicAdd(&cnt[a + (int)A.dim * c], 1);
+                    const int a = __builtin_amdgcn_readfirstlane((int)s1[x - 1]);
+                    const int c = __builtin_amdgcn_readfirstlane((int)s2[y - 1]);
+                    if (lane == 0 && a < (int)A.dim && c < (int)A.dim) atomicAdd(&cnt[a + (int)A.dim * c], 1);
                     open1 = false; open2 = false;
                     --x; --y;
                 } else if (dir == 1) {
@@ -143,7 +152,7 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                     --y;
                 }
             }
-            A.gaps[p] = gaps;
+            if (lane == 0) A.gaps[p] = gaps;
         }
     }
 }

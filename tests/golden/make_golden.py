@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures from the reference's prebuilt binary (build container only).
+
+    python tests/golden/make_golden.py [/root/reference/bin/ProGraphMSA_64]
+
+The reference cannot be compiled here (Eigen/TCLAP absent) and has no test fixtures of its own, so
+every golden vector is an output of the reference binary (rev 5e7b708) on deterministic synthetic
+inputs from tests/gen.py.  The binary never travels to the GPU box; only these small text files do.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import gen  # noqa: E402
+
+BIN = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/bin/ProGraphMSA_64"
+
+
+def run(args):
+    return subprocess.run([BIN] + args, check=True, capture_output=True, text=True).stdout
+
+
+def w(name, text):
+    with open(os.path.join(HERE, name), "w") as f:
+        f.write(text)
+
+
+def main():
+    os.chdir(HERE)
+    md5 = {}
+    # c1: 8 x 120 aa (BASELINE config 1), guide tree from the reference (-T), then --fasta --tree
+    w("c1.fa", gen.fasta(gen.gen(8, 120, 1)))
+    w("c1.tree", run(["-T", "c1.fa"]))
+    w("c1.out.fa", run(["--fasta", "--tree", "c1.tree", "c1.fa"]))
+    # c2: 64 x 400 aa (config 2)
+    w("c2.fa", gen.fasta(gen.gen(64, 400, 2)))
+    w("c2.tree", run(["-T", "-i", "0", "c2.fa"]))
+    w("c2.out.fa", run(["--fasta", "--tree", "c2.tree", "c2.fa"]))
+    # c3: 256 x 1000 aa (config 3, --mldist): the input is regenerated from the seed, tree committed,
+    # alignment pinned by md5 (838 KB of FASTA is not committed)
+    w("c3.fa.tmp", gen.fasta(gen.gen(256, 1000, 3)))
+    w("c3.tree", run(["-m", "-T", "c3.fa.tmp"]))
+    out = run(["--fasta", "-m", "-t", "c3.tree", "c3.fa.tmp"])
+    md5["c3.out.fa"] = hashlib.md5(out.encode()).hexdigest()
+    md5["c3.fa"] = hashlib.md5(open("c3.fa.tmp", "rb").read()).hexdigest()
+    # sequences starting with M exercise the start-stripping path (main.cpp:332-353)
+    seqs = gen.gen(6, 90, 11, sub=0.12, indel=0.02)
+    seqs = ["M" + s if i % 2 == 0 else s for i, s in enumerate(seqs)]
+    w("m1.fa", gen.fasta(seqs))
+    w("m1.tree", run(["-T", "-i", "0", "m1.fa"]))
+    w("m1.out.fa", run(["--fasta", "--tree", "m1.tree", "m1.fa"]))
+    # invalid residues (X / B) -> uniform profile columns
+    seqs = gen.gen(4, 70, 12, sub=0.1, indel=0.02)
+    seqs = [s[:10] + "X" + s[11:30] + "B" + s[31:] for s in seqs]
+    w("x1.fa", gen.fasta(seqs))
+    w("x1.tree", run(["-T", "-i", "0", "x1.fa"]))
+    w("x1.out.fa", run(["--fasta", "--tree", "x1.tree", "x1.fa"]))
+    # pairwise alignGraphs probes: 2 sequences + fixed 2-leaf tree (the two rows ARE mapping1/mapping2)
+    pairs = {}
+    import random
+    for seed in range(100, 124):
+        s = gen.gen(2, 80, seed, sub=0.15, indel=0.03)
+        d = random.Random(seed).uniform(0.03, 0.4)
+        fa = ">a\n%s\n>b\n%s\n" % (s[0], s[1])
+        tree = "(a:%g,b:%g);\n" % (d, d * 0.7)
+        w("pair.fa.tmp", fa)
+        w("pair.tree.tmp", tree)
+        pairs[str(seed)] = dict(fasta=fa, tree=tree, out=run(["--fasta", "--tree", "pair.tree.tmp", "pair.fa.tmp"]),
+                                out_mldist=run(["--fasta", "-m", "--tree", "pair.tree.tmp", "pair.fa.tmp"]))
+    w("pairs.json", json.dumps(pairs, indent=0))
+    # alignPair + distance estimation: -a [-m] -T -i 0 -> newick at 6 s.f. (TreeNJ.cpp:259-262)
+    nw = {}
+    for seed in range(200, 212):
+        s = gen.gen(2, 150, seed, sub=0.2, indel=0.04)
+        fa = ">a\n%s\n>b\n%s\n" % (s[0], s[1])
+        w("pair.fa.tmp", fa)
+        nw[str(seed)] = dict(fasta=fa, ml=run(["-a", "-m", "-T", "-i", "0", "pair.fa.tmp"]),
+                             pdist=run(["-a", "-T", "-i", "0", "pair.fa.tmp"]))
+    w("nw_pairs.json", json.dumps(nw, indent=0))
+    # all-pairs NW guide tree of the 8x120 family (BioNJ + midpoint root), with and without ML distances
+    w("c1.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c1.fa"]))
+    w("c1.nw_p.tree", run(["-a", "-T", "-i", "0", "c1.fa"]))
+    w("c2.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c2.fa"]))
+    # context-specific profiles: small synthetic library (K=50), 8x120 family
+    w("K50.lib", gen.genlib(50, 7))
+    w("c1.cs.out.fa", run(["--fasta", "--tree", "c1.tree", "--cs_profile", "K50.lib", "c1.fa"]))
+    w("c1.cs_ml.out.fa", run(["--fasta", "-m", "--tree", "c1.tree", "--cs_profile", "K50.lib", "c1.fa"]))
+    w("md5.json", json.dumps(md5, indent=1))
+    for f in ("c3.fa.tmp", "pair.fa.tmp", "pair.tree.tmp"):
+        os.remove(f)
+    print("golden fixtures regenerated in", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""GPU parity for the two satellite stages through the C ABI: all-pairs NW counts (bit-exact int32) and
+context-specific profiles (fp64, tolerance 1e-12 relative: only the device exp() differs from glibc)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _nw_gpu(ctx, dim, score, go, ge, syms, offs, pi, pj):
+    import prographmsa_amd as pg
+    score = np.ascontiguousarray(score, np.int32); syms = np.ascontiguousarray(syms, np.int8)
+    offs = np.ascontiguousarray(offs, np.uint32); pi = np.ascontiguousarray(pi, np.uint32); pj = np.ascontiguousarray(pj, np.uint32)
+    npairs = len(pi)
+    counts = np.full(max(1, npairs * dim * dim), -1, np.int32)
+    gaps = np.zeros(max(1, npairs), np.uint32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    pg.check(pg.lib.pgm_nw_pairs_batch(ctx.handle, dim, P(score, C.c_int32), go, ge, len(offs) - 1, P(syms, C.c_int8), P(offs, C.c_uint32),
+                                       npairs, P(pi, C.c_uint32), P(pj, C.c_uint32), P(counts, C.c_int32), P(gaps, C.c_uint32)))
+    return counts[: npairs * dim * dim].reshape(npairs, dim * dim), gaps[:npairs]
+
+
+def _score(dim, rng):
+    s = rng.integers(-4, 3, (dim + 1, dim + 1)).astype(np.int32)
+    s = np.minimum(s, s.T)
+    s[np.arange(dim + 1), np.arange(dim + 1)] = rng.integers(4, 12, dim + 1)
+    return s.reshape(-1)
+
+
+@pytest.mark.parametrize("dim", [20, 61])
+def test_nw_pairs_bit_exact(ctx, dim):
+    import oracle_lib
+    rng = np.random.default_rng(5 + dim)
+    lens = [0, 1, 2, 63, 64, 65, 127, 128, 129, 200, 333, 700]
+    base = rng.integers(0, dim, 800)
+    seqs = []
+    for L in lens:   # related sequences so that the traceback has matches, gaps and mismatches
+        s = base[:L].copy()
+        mut = rng.random(L) < 0.2
+        s[mut] = rng.integers(0, dim + 1, mut.sum())   # dim == the "invalid -> 20" style extra symbol when dim == 20
+        if L > 10:
+            cut = int(rng.integers(1, L - 5))
+            s = np.concatenate([s[:cut], s[cut + int(rng.integers(1, 5)):]])
+        seqs.append(np.minimum(s, dim).astype(np.int8))
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    syms = np.concatenate(seqs) if len(seqs) else np.zeros(0, np.int8)
+    pi, pj = zip(*[(i, j) for i in range(len(seqs)) for j in range(len(seqs)) if i != j])
+    score = _score(dim, rng)
+    cg, gg = _nw_gpu(ctx, dim, score, -10, -2, syms, offs, pi, pj)
+    co, go_ = oracle_lib.nw_pairs(dim, score, -10, -2, syms, offs, pi, pj)
+    assert np.array_equal(cg, co)
+    assert np.array_equal(gg, go_)
+
+
+def test_nw_empty(ctx):
+    c, g = _nw_gpu(ctx, 20, _score(20, np.random.default_rng(0)), -10, -2, np.zeros(4, np.int8), [0, 4], [], [])
+    assert c.size == 0 and g.size == 0
+
+
+def test_csprofile_matches_oracle(ctx):
+    import oracle_lib
+    import prographmsa_amd as pg
+    rng = np.random.default_rng(3)
+    K, ncols = 37, 13
+    p = rng.gamma(0.3, 1.0, (K, ncols, 20)) + 1e-4
+    p /= p.sum(2, keepdims=True)
+    w = 1.3 * 0.9 ** np.abs(np.arange(ncols) - ncols // 2)
+    lp = np.zeros((K, ncols, 21))
+    lp[:, :, :20] = np.log(p) * w[None, :, None]
+    centre = p[:, ncols // 2, :].copy()
+    priors = np.log(rng.dirichlet(np.ones(K)))
+    lens = [0, 1, 5, 12, 13, 14, 100, 257]
+    seqs = [rng.integers(0, 21, L).astype(np.int8) for L in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    syms = np.concatenate(seqs).astype(np.int8)
+    out_offs = np.concatenate([[0], np.cumsum([20 * (L + 2) for L in lens])]).astype(np.uint64)
+    tau = rng.uniform(0.05, 0.9, len(lens))
+    pi = rng.dirichlet(np.ones(20) * 5)
+    pu = rng.dirichlet(np.ones(20), len(lens))
+    out = np.full(int(out_offs[-1]), np.nan)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    lpf, cf, prf, puf = [np.ascontiguousarray(a, np.float64).reshape(-1) for a in (lp, centre, priors, pu)]
+    pg.check(pg.lib.pgm_csprofile_load(ctx.handle, K, ncols, P(lpf, C.c_double), P(cf, C.c_double), P(prf, C.c_double)))
+    pg.check(pg.lib.pgm_csprofile_create_batch(ctx.handle, len(lens), P(syms, C.c_int8), P(offs, C.c_uint32), P(tau, C.c_double),
+                                               P(pi, C.c_double), P(puf, C.c_double), P(out, C.c_double), P(out_offs, C.c_uint64)))
+    for s, L in enumerate(lens):
+        ref = oracle_lib.csprofile_create(K, ncols, lpf, cf, prf, seqs[s], tau[s], pi, pu[s])
+        got = out[int(out_offs[s]): int(out_offs[s + 1])]
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0)
