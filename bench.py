@@ -76,7 +76,7 @@ def main():
     if r.returncode != 0:
         raise SystemExit("pgmsa failed: " + r.stderr)
     e2e_wall = time.time() - t0
-    stats = json.loads(r.stderr.strip().splitlines()[-1])
+    stats = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
     jobs = J.load_jobs(dump)
     os.remove(dump)
     batch = J.Batch(ctx, jobs)
