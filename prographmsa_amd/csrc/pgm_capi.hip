@@ -120,17 +120,20 @@ int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count
 // ---- flattening of one graph side -------------------------------------------------------------
 namespace {
 struct SideOff {
-    size_t sites, cc, xp, xc, xv, kill, pp, pc, pv, pu;
+    size_t sites, ni, xp, xc, xv, pp, pc, pv, pu;
 };
 
 static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
     const uint32_t n = g->n;
     if (n < 2 || !g->sites || !g->e_rowptr) return PGM_ERR_INVALID;
-    std::vector<float> cc(n, INFINITY), xv, pv;
+    std::vector<float> xv, pv;
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
-    std::vector<uint8_t> kill(n, 0);
+    std::vector<PgmNodeInfo> ni(n);
     for (uint32_t v = 0; v < n; ++v) {
+        PgmNodeInfo &I = ni[v];
+        memset(&I, 0, sizeof I);
+        I.cc = INFINITY;
         const int32_t eb = g->e_rowptr[v], ee = g->e_rowptr[v + 1];
         if (eb > ee || eb < 0) return PGM_ERR_INVALID;
         for (int32_t e = eb; e < ee; ++e) {
@@ -139,7 +142,7 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
             const float c = g->e_val[e];
             const float val = (c == 0) ? INFINITY : c + 10000.0f;  // PredIterator::value, Graph.h:223-231
             pc.push_back(from); pv.push_back(val); pu.push_back(0u);
-            if (from + 1 == v && cc[v] == INFINITY && val != INFINITY) cc[v] = val;
+            if (from + 1 == v && I.cc == INFINITY && val != INFINITY) I.cc = val;
             else { xc.push_back(from); xv.push_back(val); }
         }
         if (g->r_rowptr) {
@@ -154,17 +157,36 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
         }
         xp[v + 1] = (int32_t)xc.size();
         pp[v + 1] = (int32_t)pc.size();
-        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) kill[v] = 1;
+        // summary of the extras for the on-chip (LDS history) path of the fill kernel
+        const uint32_t nx = (uint32_t)(xp[v + 1] - xp[v]);
+        uint32_t dmax = 0;
+        bool generic = nx > 3;
+        for (uint32_t k = 0; k < nx; ++k) {
+            const uint32_t d = v - xc[xp[v] + k];
+            dmax = std::max(dmax, d);
+            if (d > 255) generic = true;
+        }
+        if (!generic) {
+            I.flags = nx;
+            float *cs[3] = {&I.c1, &I.c2, &I.c3};
+            for (uint32_t k = 0; k < nx; ++k) {
+                I.dpack |= (v - xc[xp[v] + k]) << (8 * k);
+                *cs[k] = xv[xp[v] + k];
+            }
+        } else {
+            I.flags = 4u;
+        }
+        I.flags |= std::min(dmax, 255u) << 8;
+        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 8u;  // interior node without predecessors
     }
     // at least one element each so that pointers are valid
     if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
     if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
     o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);
-    o.cc = A.put(cc.data(), 4 * cc.size());
+    o.ni = A.put(ni.data(), sizeof(PgmNodeInfo) * ni.size());
     o.xp = A.put(xp.data(), 4 * xp.size());
     o.xc = A.put(xc.data(), 4 * xc.size());
     o.xv = A.put(xv.data(), 4 * xv.size());
-    o.kill = A.put(kill.data(), kill.size());
     o.pp = A.put(pp.data(), 4 * pp.size());
     o.pc = A.put(pc.data(), 4 * pc.size());
     o.pv = A.put(pv.data(), 4 * pv.size());
@@ -172,13 +194,15 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     return PGM_OK;
 }
 
-template <int DP, int NW, int R>
+template <int DP, int NW>
 static hipError_t launch_fill(const pgm_align_batch *b, hipStream_t s) {
-    constexpr int NQ = DP / 4 + 1;
-    const size_t lds = (size_t)NW * R * NQ * sizeof(float4) + (size_t)((b->maxnb + 3) / 4 * 4) * sizeof(int);
-    hipError_t e = hipFuncSetAttribute((const void *)pgm_fill_kernel<DP, NW, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    constexpr int NQ = DP / 4 + 2;
+    constexpr size_t wave_lds = (size_t)PGM_RING * NQ * 16 + 3 * PGM_HIST * 64 * 4 + PGM_BLOCK * PGM_HALO * 8;
+    const size_t lds = NW * wave_lds + (size_t)((b->maxnb + 3) / 4 * 4) * sizeof(int);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)pgm_fill_kernel<DP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pgm_fill_kernel<DP, NW, R>), dim3(b->njobs), dim3(NW * 64), lds, s, b->d_jobs, b->d_order);
+    hipLaunchKernelGGL((pgm_fill_kernel<DP, NW>), dim3(b->njobs), dim3(NW * 64), lds, s, b->d_jobs, b->d_order);
     return hipGetLastError();
 }
 
@@ -190,8 +214,8 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipLaunchKernelGGL(pgm_prep_kernel, dim3(b->njobs, 2), dim3(256), prep_lds, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
-    if (b->maxdim <= 20) e = launch_fill<20, 8, 128>(b, s);
-    else e = launch_fill<64, 4, 128>(b, s);
+    if (b->maxdim <= 20) e = launch_fill<20, 6>(b, s);
+    else e = launch_fill<64, 4>(b, s);
     if (e != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
     hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(64), 0, s, b->d_jobs);
@@ -213,7 +237,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->jobs.resize(njobs);
     Arena A;
     DevLayout W, C, O;
-    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, brow, map1, map2, ms, mp, res, cells; };
+    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
     for (uint32_t i = 0; i < njobs; ++i) {
@@ -226,7 +250,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         memset(&J, 0, sizeof J);
         J.n1 = a->n; J.n2 = c->n; J.dim = a->dim;
         J.dp = a->dim <= 20 ? 20 : 64;
-        J.nb = (a->n - 1 + 63) / 64;
+        J.nb = (a->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
         J.ncol = c->n - 1;
         J.tsteps = J.ncol + 63;
         J.maxn = std::max(a->n, c->n);
@@ -244,8 +268,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
         o.a1 = W.take(sizeof(float) * J.n1);
         o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
-        o.aux2 = W.take(sizeof(float4) * J.n2);
-        o.brow = W.take(sizeof(float2) * (size_t)J.nb * J.ncol);
+        o.aux2 = W.take(sizeof(float4) * 2 * (size_t)J.n2);
         o.map1 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.map2 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.ms = W.take(4 * (size_t)J.maxn);
@@ -271,18 +294,16 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         uint8_t *in = b->d_in, *w = b->d_work, *ob = b->d_out;
         J.sites1 = (const double *)(in + o.s1.sites); J.sites2 = (const double *)(in + o.s2.sites);
         J.M = (const double *)(in + o.M); J.pi = (const double *)(in + o.pi);
-        J.cc1 = (const float *)(in + o.s1.cc); J.cc2 = (const float *)(in + o.s2.cc);
+        J.ni1 = (const PgmNodeInfo *)(in + o.s1.ni); J.ni2 = (const PgmNodeInfo *)(in + o.s2.ni);
         J.xp1 = (const int32_t *)(in + o.s1.xp); J.xp2 = (const int32_t *)(in + o.s2.xp);
         J.xc1 = (const uint32_t *)(in + o.s1.xc); J.xc2 = (const uint32_t *)(in + o.s2.xc);
         J.xv1 = (const float *)(in + o.s1.xv); J.xv2 = (const float *)(in + o.s2.xv);
-        J.kill1 = in + o.s1.kill; J.kill2 = in + o.s2.kill;
         J.pp1 = (const int32_t *)(in + o.s1.pp); J.pp2 = (const int32_t *)(in + o.s2.pp);
         J.pc1 = (const uint32_t *)(in + o.s1.pc); J.pc2 = (const uint32_t *)(in + o.s2.pc);
         J.pv1 = (const float *)(in + o.s1.pv); J.pv2 = (const float *)(in + o.s2.pv);
         J.pu1 = (const uint32_t *)(in + o.s1.pu); J.pu2 = (const uint32_t *)(in + o.s2.pu);
         J.g1f = (float *)(w + o.g1f); J.a1 = (float *)(w + o.a1);
         J.t2 = (float *)(w + o.t2); J.aux2 = (float4 *)(w + o.aux2);
-        J.brow = (float2 *)(w + o.brow);
         J.map1 = (uint32_t *)(ob + o.map1); J.map2 = (uint32_t *)(ob + o.map2);
         J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
         J.result = (PgmJob::Result *)(ob + o.res);
@@ -401,13 +422,13 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
             if (dst[k]) std::fill(dst[k], dst[k] + N, -INFINITY);
         for (uint32_t y = 0; y + 1 < J.n1; ++y)
             for (uint32_t x = 0; x < J.ncol; ++x) {
-                const uint32_t bb = y >> 6, l = y & 63u;
-                const float4 c = cells[((size_t)bb * J.tsteps + (x + l)) * 64u + l];
+                const uint32_t bb = y / PGM_ROWS, l = PGM_HALO + (y - bb * PGM_ROWS);
+                const float4 c = cells[((size_t)bb * J.tsteps + (x + l)) * 64u + l];  // {M, X, W, Y}
                 const size_t i = (size_t)y + (size_t)J.n1 * x;
                 if (M) M[i] = c.x;
                 if (X) X[i] = c.y;
-                if (Y) Y[i] = c.z;
-                if (W) W[i] = c.w;
+                if (Y) Y[i] = c.w;
+                if (W) W[i] = c.z;
             }
     }
     if (S) {
