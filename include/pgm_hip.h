@@ -98,7 +98,7 @@ int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 
 /* Staged form of the same call (what pgm_align_graphs_batch does internally):
  *   create  : flatten + upload every job's inputs to HBM, allocate the DP storage
- *   run     : launch prep + fill + traceback kernels on the context's stream (asynchronous)
+ *   run     : launch prep + emission + fill + traceback kernels on the context's stream (asynchronous)
  *   fetch   : wait, copy score / mappings back into caller memory
  * bench.py times `run` with the inputs already resident. */
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
@@ -110,9 +110,10 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);
 /* Σ (n1-2)(n2-2) over the jobs of the batch (the GCUPS numerator). */
 uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
 /* Run the batch `reps` times back to back and return the mean device time in milliseconds of
- * each kernel stage, measured with HIP events on the context's stream. */
+ * each kernel stage (prep, emission scores, DP fill, traceback), measured with HIP events on
+ * the context's stream. */
 int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
-                         float *ms_fill, float *ms_traceback);
+                         float *ms_emission, float *ms_fill, float *ms_traceback);
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
  * column-major, element (y,x) at y + x*n1).  Only rows < n1-1 and columns < n2-1 are
  * defined (the END row/column are never written by the reference's fill either).

@@ -67,7 +67,7 @@ def _load():
         "pgm_align_batch_fetch": (C.c_int, [vp, vp, C.POINTER(pgm_align_out)]),
         "pgm_align_batch_destroy": (None, [vp, vp]),
         "pgm_align_batch_cells": (C.c_uint64, [vp]),
-        "pgm_align_batch_time": (C.c_int, [vp, vp, C.c_int] + [C.POINTER(C.c_float)] * 3),
+        "pgm_align_batch_time": (C.c_int, [vp, vp, C.c_int] + [C.POINTER(C.c_float)] * 4),
         "pgm_align_batch_read_matrices": (C.c_int, [vp, vp, u32] + [C.POINTER(C.c_float)] * 5),
         "pgm_nw_pairs_batch": (C.c_int, [vp, u32, C.POINTER(i32), i32, i32, u32, C.POINTER(C.c_int8), C.POINTER(u32), u32,
                                          C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "pgm_device.h"
 
 #define PGM_NEG_INF (-INFINITY)
@@ -44,7 +45,7 @@ __device__ __forceinline__ float pgm_emission_finish(float num, float ay, float 
 // ---------------------------------------------------------------------------------------------
 // Prep kernel: float casts, T = M^T g2, per-node denominators.  grid = (njobs, 2), block = 256.
 //   side 0: g1f[y][k] = float(sites1(k,y));  a1[y] = sum_k g1f[y][k] * pi_f[k]
-//   side 1: t2[x][k]  = sum_j M_f(j,k) * g2f(j,x);  aux2[x] = {sum_k pi_f[k] g2f(k,x), PgmNodeInfo of column x}
+//   side 1: t2[x][k]  = sum_j M_f(j,k) * g2f(j,x);  b2[x] = sum_k pi_f[k] g2f(k,x)
 __global__ void __launch_bounds__(256) pgm_prep_kernel(const PgmJob *__restrict__ jobs) {
     extern __shared__ float prep_lds[];  // Mf (dim*dim) then pif (dim)
     const PgmJob &J = jobs[blockIdx.x];
@@ -79,14 +80,7 @@ __global__ void __launch_bounds__(256) pgm_prep_kernel(const PgmJob *__restrict_
             for (uint32_t k = D; k < DP; ++k) dst[k] = 0.0f;
             float b = 0.0f;
             for (uint32_t k = 0; k < D; ++k) b = __fadd_rn(b, __fmul_rn(pif[k], (float)col[k]));
-            const PgmNodeInfo ni = J.ni2[x];
-            float4 a;
-            a.x = b;
-            a.y = ni.cc;
-            a.z = __uint_as_float(ni.flags);
-            a.w = __uint_as_float(ni.dpack);
-            J.aux2[2 * x] = a;
-            J.aux2[2 * x + 1] = make_float4(ni.c1, ni.c2, ni.c3, 0.0f);
+            J.b2[x] = b;
         }
     }
 }
@@ -107,104 +101,201 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Emission kernel (GraphAlign.h:145-163 precomputeScores, fused with ls_log_add): S for every cell, written
+// in the skewed (band, step, lane) order in which the fill kernel consumes it.  No dependencies between
+// cells, so this part of the reference's per-cell work runs at full occupancy, off the DP's critical path.
+// grid = (nblk chunks of 4 blocks, nb, njobs); block = 256 threads = 4 wavefronts, wavefront w owns the
+// 16-step block 4*blockIdx.x + w of band blockIdx.y; lane l >= 16 owns row y = 48 b + l - 16 and computes
+// its 16 cells (columns t - l).  The 127 columns of T = M^T g2 the workgroup touches are staged in LDS.
+template <int DP>
+__global__ void __launch_bounds__(256) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
+    constexpr int NT = DP / 4;
+    constexpr int COLS = 64 + 4 * PGM_BLOCK - 1;   // columns [t0 - 63, t0 + 63]
+    __shared__ float4 tq[COLS * NT];
+    __shared__ float bq[COLS];
+    const PgmJob &J = jobs[blockIdx.z];
+    const uint32_t b = blockIdx.y;
+    if (b >= J.nb) return;
+    const uint32_t t0 = blockIdx.x * 4u * PGM_BLOCK;
+    if (t0 >= J.tsteps) return;
+    const int cbase = (int)t0 - 63;
+    const float4 *t2q = (const float4 *)J.t2;
+    for (int i = threadIdx.x; i < COLS * NT; i += 256) {
+        const int col = cbase + i / NT;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col >= 0 && col <= (int)J.ncol) v = t2q[(size_t)NT * col + (i % NT)];
+        tq[i] = v;
+    }
+    for (int i = threadIdx.x; i < COLS; i += 256) {
+        const int col = cbase + i;
+        bq[i] = (col >= 0 && col <= (int)J.ncol) ? J.b2[col] : 0.f;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tb = blockIdx.x * 4u + wave;
+    if (tb >= J.nblk || lane < PGM_HALO) return;
+    const uint32_t y = PGM_ROWS * b + (uint32_t)(lane - PGM_HALO);
+    const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
+    float gy[DP];
+    {
+        const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const float4 v = src[q];
+            gy[4 * q] = v.x; gy[4 * q + 1] = v.y; gy[4 * q + 2] = v.z; gy[4 * q + 3] = v.w;
+        }
+    }
+    const float ay = J.a1[yc];
+    const float mi = J.sc.match_init;
+    float out[PGM_BLOCK];
+#pragma unroll
+    for (int i = 0; i < PGM_BLOCK; ++i) {
+        const int t = (int)(tb * PGM_BLOCK) + i;
+        int ci = t - lane - cbase;            // index into the staged window, in [0, COLS) whenever x >= cbase
+        ci = ci < 0 ? 0 : (ci >= COLS ? COLS - 1 : ci);
+        const float4 *tc = tq + ci * NT;
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const float4 tv = tc[q];
+            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q], tv.x));
+            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 1], tv.y));
+            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 2], tv.z));
+            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 3], tv.w));
+        }
+        out[i] = pgm_emission_finish(acc, ay, bq[ci], mi);
+    }
+    float4 *dst = (float4 *)(J.S + (((size_t)b * J.nblk + tb) * 64u + (uint32_t)lane) * PGM_BLOCK);
+#pragma unroll
+    for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
+// wave-uniform maximum of a per-lane value in 0..7 (three ballots, no cross-lane data movement)
+__device__ __forceinline__ int pgm_wave_max8(uint32_t v) {
+    int m = __builtin_amdgcn_ballot_w64(v >= 4u) != 0 ? 4 : 0;
+    m += __builtin_amdgcn_ballot_w64(v >= (uint32_t)(m + 2)) != 0 ? 2 : 0;
+    m += __builtin_amdgcn_ballot_w64(v >= (uint32_t)(m + 1)) != 0 ? 1 : 0;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-wide (agent scope) accesses to the DP storage: a band may be continued on another CU / XCD, whose L1
+// never sees our stores and whose L2 is not coherent with ours, so cells are written through (sc1) and read
+// with L1-bypassing loads; the hand-off itself is the progress counter below (MI355X guide, Guideline 16 R1).
+__device__ __forceinline__ void pgm_store_cell(float4 *p, float Mv, float Xv, float Wv, float Yv) {
+    // one 16-byte write-through store (sc1 = device scope): `global_store_dwordx4 ... sc1`.  hipcc does not count
+    // inline-asm memory operations in its own s_waitcnt bookkeeping; an uncounted extra store only makes the
+    // compiler's counted waits stricter (vmcnt retires in issue order), never weaker.
+    typedef float pgm_v4f __attribute__((ext_vector_type(4)));
+    pgm_v4f v;
+    v.x = Mv; v.y = Xv; v.z = Wv; v.w = Yv;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ float2 pgm_load_cell_mx(const float4 *p) {   // {M, X}
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+}
+__device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y}
+    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fill kernel (GraphAlign.h:212-260 incl. the border initialisation as row/column 0).
 //
-// One workgroup per job, NW wavefronts; wavefront w sweeps the row bands w, w+NW, ...  A band is 48
-// rows: lanes 16..63 own rows y = 48 b + l - 16 and at step t compute column x = t - l, so the three
-// chain neighbours (y-1,x-1), (y-1,x), (y,x-1) are in registers of lane l-1 (one DPP shift) or of the
-// lane itself.  Lanes 0..15 do not compute: they REPLAY the last 16 rows of band b-1 (read back from
-// the cell storage, one contiguous 256 B run per step, staged through LDS a block ahead), so that
-// every predecessor row within 16 rows of a lane lives in a lower lane of the same wavefront.
+// Persistent grid of single-wavefront workers (64-thread workgroups, all co-resident).  A job is swept by
+// `nworkers` workers; worker `rank` takes the row bands rank, rank + nworkers, ...  A band is 48 rows: lanes
+// 16..63 own rows y = 48 b + l - 16 and at step t compute column x = t - l, so the three chain neighbours
+// (y-1,x-1), (y-1,x), (y,x-1) are in registers of lane l-1 (one DPP shift) or of the lane itself.  Lanes 0..15
+// do not compute: they REPLAY the last 16 rows of band b-1 (read back from the cell storage, one contiguous
+// 256 B run per step, staged through LDS a block ahead), so that every predecessor row within 16 rows of a
+// lane lives in a lower lane of the same wavefront.
 //
-// Per-wavefront LDS (no LDS is shared between wavefronts except the progress counters):
-//   ring  : the last 80 columns of T = M^T g2 plus the per-column predecessor summary (refilled 16
-//           columns at a time, loaded one block ahead)
-//   hW/hY/hX : W, Y, X of all 64 lanes for the last 16 steps.  A skip-edge predecessor pair
+// Per-wavefront LDS:
+//   ring  : predecessor summary (PgmNodeInfo) of the last 80 columns, loaded one 16-column block ahead
+//   hW/hY/hX : W of all 64 lanes for the last 32 steps, Y and X for the last 16.  A skip-edge predecessor pair
 //           (y-dy, x-dx) was produced by lane l-dy exactly dy+dx steps ago, so merged-graph skip edges
 //           (distances of a few nodes) are served from this history without touching HBM.
-//   rep   : replay values {W,Y} of the next 16 steps
-// Predecessor pairs that reach further than the history (dy+dx > 15), nodes with more than 3 extra
-// predecessors and tandem-repeat edges far back fall back to reading the cell storage (HBM/L2).
-// Bands hand over through the cell storage itself; prog[b] (LDS) = number of steps of band b that
-// are complete AND visible (the producer publishes behind a counted s_waitcnt, never vmcnt(0)).
-template <int DP, int NW>
-__global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const uint32_t *__restrict__ order) {
-    constexpr int NT = DP / 4;       // float4 of T per column
-    constexpr int NQ = NT + 2;       // + {b, cc, flags, dpack} + {c1, c2, c3, -}
-    constexpr int R = PGM_RING, H = PGM_HIST, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
-    constexpr int WAVE_LDS = R * NQ * 16 + 3 * H * 64 * 4 + BL * HR * 8;  // bytes
-    static_assert(WAVE_LDS % 16 == 0, "LDS carve must stay 16-byte aligned");
-    constexpr int PFQ = (BL * NQ + 63) / 64;   // ring prefetch quads per lane
-    extern __shared__ __attribute__((aligned(16))) unsigned char fill_lds[];
-    const PgmJob &J = jobs[order[blockIdx.x]];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned char *wl = fill_lds + (size_t)wave * WAVE_LDS;
-    float4 *ring = (float4 *)wl;
-    float *hW = (float *)(wl + R * NQ * 16);
-    float *hY = hW + H * 64;
-    float *hX = hY + H * 64;
-    float2 *rep = (float2 *)(hX + H * 64);
-    int *prog = (int *)(fill_lds + (size_t)NW * WAVE_LDS);
+//   rep   : replay values {W,Y} of the current 16 steps;  sblk : emission scores of the current 16 steps
+// Nodes with a predecessor more than 15 nodes back or with more than 7 extra predecessors (far tandem-repeat
+// edges, pathological graphs) fall back to reading the cell storage (HBM/L2) for all their extras.
+// Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
+// that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
+#define PGM_SPIN_LIMIT (1u << 24)
 
-    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb;
-    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, mi = J.sc.match_init, s_init = J.sc.start_init;
-    const float4 *t2q = (const float4 *)J.t2;
+template <int DUMMY>
+__global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmWorker *__restrict__ workers,
+                                                      int *__restrict__ abort_flag) {
+    constexpr int NQ = 4;            // PgmNodeInfo of a column = 4 float4
+    constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
+    constexpr int PFQ = (BL * NQ + 63) / 64;   // ring prefetch quads per lane (= 1)
+    __shared__ __attribute__((aligned(16))) float4 ring[R * NQ];
+    __shared__ float hW[HW * 64];
+    __shared__ float hY[H * 64];
+    __shared__ float hX[H * 64];
+    static_assert(PGM_HIST == PGM_HISTW, "all three history planes share one depth");
+    __shared__ float2 rep[BL * HR];
+    __shared__ float sblk[BL * 64];
 
-    for (uint32_t i = threadIdx.x; i < nb; i += NW * 64) prog[i] = 0;
-    __syncthreads();
+    const PgmWorker wk = workers[blockIdx.x];
+    const PgmJob &J = jobs[wk.job];
+    const int lane = threadIdx.x;
+    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
+    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
+    bool aborted = false;
+    for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (uint32_t b = wave; b < nb; b += NW) {
+    for (uint32_t b = wk.rank; b < nb && !aborted; b += wk.nworkers) {
         const bool comp = lane >= HR;                       // compute lane (else replay lane)
         const uint32_t y = RC * b + (uint32_t)(lane - HR);  // only meaningful for compute lanes
         const bool rowvalid = comp && y + 1 < n1;           // rows 0..n1-2
         const uint32_t yc = rowvalid ? y : 0u;
-        float gy[DP];
-        {
-            const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                const float4 v = src[q];
-                gy[4 * q] = v.x; gy[4 * q + 1] = v.y; gy[4 * q + 2] = v.z; gy[4 * q + 3] = v.w;
-            }
-        }
-        const float ay = J.a1[yc];
         const PgmNodeInfo niy = J.ni1[yc];
         const float ccy = niy.cc;
         const uint32_t fy = rowvalid ? niy.flags : 0u;
-        const uint32_t nyl = fy & 3u;
-        const bool geny = (fy & 4u) != 0;
-        const bool ykill = (fy & 8u) != 0;
         const uint32_t dymax = (fy >> 8) & 255u;
-        const uint32_t dpy = niy.dpack;
-        const float cy1 = niy.c1, cy2 = niy.c2, cy3 = niy.c3;
+        // a row whose furthest extra predecessor lies above lane 0 of this wavefront cannot use the on-chip history
+        const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
+        const bool ykill = (fy & 16u) != 0;
+        // row extras as lane constants: rk8 = dy << 8 (history slot stride is 256 B), lk4 = byte offset of the source
+        // lane inside a slot, cyv = cost (+inf for an absent extra, which turns its terms into -inf)
+        uint32_t rk8[PGM_KX], lk4[PGM_KX];
+        float cyv[PGM_KX];
+#pragma unroll
+        for (int k = 0; k < PGM_KX; ++k) {
+            rk8[k] = (rowvalid && !geny) ? niy.d[k] : 0u;
+            cyv[k] = (rowvalid && !geny) ? niy.c[k] : INFINITY;
+            lk4[k] = (uint32_t)(lane * 4) - (rk8[k] >> 6);
+        }
+        const int nyw = pgm_wave_max8(geny ? 0u : (fy & 7u));   // band constant: most extras any row of this band has
         const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
         const float gopen_x = (rowvalid && y == 0) ? sg : gi;  // row 0 opens gaps with start_gap (GraphAlign.h:229)
         const bool has_next = (b + 1 < nb);
         const bool has_prev = (b > 0);
         float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
         const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;  // only dereferenced if has_prev
+        const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
+        const float4 *ni2q = (const float4 *)J.ni2;
 
         // history planes start at -inf (no NaN may ever be read from them)
-        for (int i = lane; i < 3 * H * 64; i += 64) hW[i] = PGM_NEG_INF;
+        for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
+        for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
 
         float W_left = PGM_NEG_INF, X_left = PGM_NEG_INF, W_diag = PGM_NEG_INF;
         float W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
         int xr = (R - lane) % R;   // ring slot of this lane's column, advanced every step
 
-        // ---- prefetch state -------------------------------------------------------------------
-        float4 pfq[PFQ];           // ring columns [t0+16, t0+32) loaded during block t0
-        float2 pfr[4];             // replay tile of block t0+16 loaded during block t0
+        // ---- data of the next block, in flight while the current block is computed -----------------
+        float4 pfq[PFQ];           // column summaries [c0, c0+16)
+        float2 pfr[4];             // replay tile
+        float4 pfs[BL / 4];        // emission scores of this lane
         auto load_ring_block = [&](uint32_t c0) {
 #pragma unroll
             for (int u = 0; u < PFQ; ++u) {
                 const int idx = lane + 64 * u;
                 const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                const int q = idx % NQ;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < BL * NQ && col <= ncol) {
-                    if (q < NT) v = t2q[(size_t)NT * col + q];
-                    else v = J.aux2[2 * col + (q - NT)];
-                }
+                if (idx < BL * NQ && col <= ncol) v = ni2q[(size_t)NQ * col + (idx % NQ)];
                 pfq[u] = v;
             }
         };
@@ -213,8 +304,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
             for (int u = 0; u < PFQ; ++u) {
                 const int idx = lane + 64 * u;
                 const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                const int q = idx % NQ;
-                if (idx < BL * NQ) ring[(size_t)(col % R) * NQ + q] = pfq[u];
+                if (idx < BL * NQ) ring[(col % R) * NQ + (idx % NQ)] = pfq[u];
             }
         };
         // replay tile of the 16 steps starting at s0: element e = i*16 + l -> {W,Y} of band b-1, step s0+i+48, lane 48+l
@@ -225,10 +315,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
                 const uint32_t st = s0 + (uint32_t)(e >> 4) + (uint32_t)RC;
                 const int l = e & 15;
                 float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
-                if (has_prev && st < tsteps) {
-                    const float4 c = cells_prev[(size_t)st * 64u + (uint32_t)(RC + l)];
-                    v = make_float2(c.z, c.w);
-                }
+                if (has_prev && st < tsteps) v = pgm_load_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
                 pfr[u] = v;
             }
         };
@@ -236,30 +323,59 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) rep[lane * 4 + u] = pfr[u];
         };
+        auto load_s_block = [&](uint32_t s0) {
+            const uint32_t tb = s0 / BL;
+#pragma unroll
+            for (int q = 0; q < BL / 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (comp && tb < nblk) v = S_band[((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q];
+                pfs[q] = v;
+            }
+        };
+        auto store_s_block = [&]() {
+#pragma unroll
+            for (int q = 0; q < BL / 4; ++q) {
+                sblk[(4 * q) * 64 + lane] = pfs[q].x;
+                sblk[(4 * q + 1) * 64 + lane] = pfs[q].y;
+                sblk[(4 * q + 2) * 64 + lane] = pfs[q].z;
+                sblk[(4 * q + 3) * 64 + lane] = pfs[q].w;
+            }
+        };
         auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
-            if (has_prev) {
+            if (has_prev && !aborted) {
                 const int need = (int)min(steps_needed, tsteps);
-                while (__hip_atomic_load(&prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                    __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t spins = 0;
+                while (__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                        break;
+                    }
+                }
             }
         };
 
         // prologue: data of block 0 straight in, data of block 1 in flight
         load_ring_block(0);
         store_ring_block(0);
+        load_s_block(0);
+        store_s_block();
         wait_prev(BL + RC + BL);
         load_rep_block(0);
         store_rep_block();
         load_ring_block(BL);
+        load_s_block(BL);
         load_rep_block(BL);
 
-        for (uint32_t t0 = 0; t0 < tsteps; t0 += BL) {
+        for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
             if (t0 > 0) {
                 // data loaded during the previous block becomes current; start loading the next block
                 store_ring_block(t0);
                 store_rep_block();
+                store_s_block();
                 load_ring_block(t0 + BL);
+                load_s_block(t0 + BL);
                 wait_prev(t0 + BL + BL + RC);   // replay tile of block t0+16 reads steps < t0+16+16+48 of band b-1
                 load_rep_block(t0 + BL);
             }
@@ -270,26 +386,14 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
                 const bool incol = xs >= 0 && xs < (int)ncol;
                 const bool active = rowvalid && incol;
                 const uint32_t x = (uint32_t)xs;
-                const float4 *rc = ring + (size_t)xr * NQ;
+                const float4 *rc = ring + xr * NQ;
                 xr = (xr + 1 == R) ? 0 : xr + 1;
-                const float4 aux = rc[NT];
-                float acc = 0.0f;
-#pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    const float4 tv = rc[q];
-                    acc = __fadd_rn(acc, __fmul_rn(gy[4 * q], tv.x));
-                    acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 1], tv.y));
-                    acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 2], tv.z));
-                    acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 3], tv.w));
-                }
-                const float S = pgm_emission_finish(acc, ay, aux.x, mi);
-                const float ccx = aux.y;
-                const uint32_t fx = active ? __float_as_uint(aux.z) : 0u;
-                const uint32_t dpx = __float_as_uint(aux.w);
-                const uint32_t nxl = fx & 3u;
-                const bool genx = (fx & 4u) != 0;
-                const bool xkill = (fx & 8u) != 0;
-                const uint32_t dxmax = (fx >> 8) & 255u;
+                const float4 aux = rc[0];   // {cc, flags, d0, d1} of column x
+                const float S = sblk[i * 64 + lane];
+                const float ccx = aux.x;
+                const uint32_t fx = __float_as_uint(aux.y);
+                const bool genx = active && (fx & 8u) != 0;
+                const bool xkill = active && (fx & 16u) != 0;
                 const float gopen_y = (xs == 0) ? sg : gi;  // column 0 opens gaps with start_gap (:218)
 
                 const float W_up = pgm_dpp_wave_shr1(W_o, PGM_NEG_INF);
@@ -300,85 +404,93 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
                 float Xv = __fsub_rn(fmaxf(__fadd_rn(X_left, ge), __fadd_rn(W_left, gopen_x)), ccx);
                 float Yv = __fsub_rn(fmaxf(__fadd_rn(Y_up, ge), __fadd_rn(W_up, gopen_y)), ccy);
 
-                const bool anyex = active && ((nyl | nxl) != 0 || geny || genx);
-                if (__builtin_amdgcn_ballot_w64(anyex) != 0) {
-                    const uint32_t reach = max(dymax, 1u) + max(dxmax, 1u);
-                    const bool gen = anyex && (geny || genx || reach > (uint32_t)(H - 1));
-                    const bool near = anyex && !gen;
-                    if (__builtin_amdgcn_ballot_w64(near) != 0) {
-                        const float4 cxs = rc[NT + 1];
-                        // row extras k = 0..2 (distance dyk, cost cyk)
+                // ---- skip-edge predecessors served from the LDS history --------------------------------------
+                // Everything below is branch-free per lane: an absent extra has cost +inf and distance 0, so its
+                // term evaluates to -inf.  nyw / nxw (wave-uniform maxima) only bound the unrolled loops.
+                const int nxw = pgm_wave_max8(fx & 7u);
+                // a pair (dy, dx) reaches dy+dx steps back; beyond the history depth the lane-step goes generic
+                const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
+                float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF, Yn = PGM_NEG_INF;
+                if (nyw > 0 || nxw > 0) {
+                    const uint32_t t8 = t << 8;
+                    const uint32_t lane4 = (uint32_t)lane * 4u;
+                    const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
+                    constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
+                    uint32_t cj8[PGM_KX];
+                    float cxv[PGM_KX];
+                    if (nxw > 0) {
+                        const float4 q1 = rc[1], q2 = rc[2], q3 = rc[3];
+                        cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
+                        cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
+                        cj8[6] = __float_as_uint(q2.x);
+                        cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
+                        // column extras: X term and the M term with the chain row (source lane l-1)
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const bool mk = near && (uint32_t)k < nyl;
-                            if (__builtin_amdgcn_ballot_w64(mk) != 0) {
-                                const uint32_t dyk = (dpy >> (8 * k)) & 255u;
-                                const float cyk = k == 0 ? cy1 : (k == 1 ? cy2 : cy3);
-                                if (mk) {
-                                    const int sl = lane - (int)dyk;
-                                    const int o0 = (int)(((t - dyk) & (H - 1)) << 6) + sl;
-                                    const float Wk = hW[o0], Yk = hY[o0];
-                                    Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y)), cyk));
-                                    const float W1 = hW[(int)(((t - dyk - 1u) & (H - 1)) << 6) + sl];
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), cyk), ccx));
-#pragma unroll
-                                    for (int j = 0; j < 3; ++j) {
-                                        if ((uint32_t)j < nxl) {
-                                            const uint32_t dxj = (dpx >> (8 * j)) & 255u;
-                                            const float cxj = j == 0 ? cxs.x : (j == 1 ? cxs.y : cxs.z);
-                                            const float W2 = hW[(int)(((t - dyk - dxj) & (H - 1)) << 6) + sl];
-                                            Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyk), cxj));
-                                        }
-                                    }
-                                }
+                        for (int j = 0; j < PGM_KX; ++j) {
+                            if (j < nxw) {
+                                const uint32_t tj8 = t8 - cj8[j];
+                                const float Wj = *(const float *)(hWb + ((tj8 & MW) | lane4));
+                                const float Xj = *(const float *)(hXb + ((tj8 & MH) | lane4));
+                                const float W1 = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
+                                Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj, ge), __fadd_rn(Wj, gopen_x)), cxv[j]));
+                                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cxv[j]));
                             }
                         }
-                        // column extras j = 0..2 (distance dxj, cost cxj)
+                    }
+                    // row extras: Y term, M term with the chain column, M terms with every column extra
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const bool mj = near && (uint32_t)j < nxl;
-                            if (__builtin_amdgcn_ballot_w64(mj) != 0) {
-                                const uint32_t dxj = (dpx >> (8 * j)) & 255u;
-                                const float cxj = j == 0 ? cxs.x : (j == 1 ? cxs.y : cxs.z);
-                                if (mj) {
-                                    const int o0 = (int)(((t - dxj) & (H - 1)) << 6) + lane;
-                                    const float Wj = hW[o0], Xj = hX[o0];
-                                    Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(Xj, ge), __fadd_rn(Wj, gopen_x)), cxj));
-                                    const float W1 = hW[(int)(((t - 1u - dxj) & (H - 1)) << 6) + lane - 1];
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cxj));
+                    for (int k = 0; k < PGM_KX; ++k) {
+                        if (k < nyw) {
+                            const uint32_t tk8 = t8 - rk8[k];
+                            const float Wk = *(const float *)(hWb + ((tk8 & MW) | lk4[k]));
+                            const float Yk = *(const float *)(hYb + ((tk8 & MH) | lk4[k]));
+                            const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | lk4[k]));
+                            Yn = fmaxf(Yn, __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y)), cyv[k]));
+                            Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), cyv[k]), ccx));
+                            // pairs with the column extras: bounded by the most column extras among the lanes that
+                            // actually have a k-th row extra (few lanes for k >= 1)
+                            const int nxk = (k == 0 || nxw == 0) ? nxw : pgm_wave_max8(rk8[k] != 0u ? (fx & 7u) : 0u);
+#pragma unroll
+                            for (int j = 0; j < PGM_KX; ++j) {
+                                if (j < nxk) {
+                                    const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
+                                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
                                 }
                             }
                         }
                     }
-                    if (__builtin_amdgcn_ballot_w64(gen) != 0) {
-                        // far / many predecessors: every non-chain pair from the cell storage (HBM/L2)
-                        if (gen) {
-                            const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
-                            for (uint32_t e = xby; e < xey; ++e) {
-                                const uint32_t yp = J.xc1[e];
-                                const float cy = J.xv1[e];
-                                const float4 c = pgm_load_cell(J, yp, x);
-                                Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.w, ge), __fadd_rn(c.z, gopen_y)), cy));
-                                if (x > 0) {
-                                    const float4 c2 = pgm_load_cell(J, yp, x - 1);
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.z, S), cy), ccx));
-                                }
-                                for (uint32_t f = xbx; f < xex; ++f) {
-                                    const uint32_t xp = J.xc2[f];
-                                    const float cx = J.xv2[f];
-                                    const float4 c3 = pgm_load_cell(J, yp, xp);
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.z, S), cy), cx));
-                                }
+                    if (!overflow) { Mv = fmaxf(Mv, Mn); Xv = fmaxf(Xv, Xn); Yv = fmaxf(Yv, Yn); }
+                }
+                // ---- far / many predecessors: every non-chain pair from the cell storage (HBM/L2) ---------------
+                const bool gen = active && (geny || genx || overflow);
+                if (__builtin_amdgcn_ballot_w64(gen) != 0) {
+                    if (gen) {
+                        const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
+                        for (uint32_t e = xby; e < xey; ++e) {
+                            const uint32_t yp = J.xc1[e];
+                            const float cy = J.xv1[e];
+                            const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
+                            Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
+                            if (x > 0) {
+                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x - 1));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
                             }
                             for (uint32_t f = xbx; f < xex; ++f) {
                                 const uint32_t xp = J.xc2[f];
                                 const float cx = J.xv2[f];
-                                const float4 c = pgm_load_cell(J, y, xp);
-                                Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.z, gopen_x)), cx));
-                                if (y > 0) {
-                                    const float4 c2 = pgm_load_cell(J, y - 1, xp);
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.z, S), ccy), cx));
-                                }
+                                const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
+                            }
+                        }
+                        for (uint32_t f = xbx; f < xex; ++f) {
+                            const uint32_t xp = J.xc2[f];
+                            const float cx = J.xv2[f];
+                            const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
+                            const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
+                            Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
+                            if (y > 0) {
+                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, y - 1, xp));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), ccy), cx));
                             }
                         }
                     }
@@ -395,30 +507,30 @@ __global__ void __launch_bounds__(NW * 64) pgm_fill_kernel(const PgmJob *__restr
                     Yv = incol ? rv.y : PGM_NEG_INF;
                 }
                 if (active) {
-                    float4 cell;
-                    cell.x = Mv; cell.y = Xv; cell.z = Wv; cell.w = Yv;
-                    cells_band[(size_t)t * 64u + lane] = cell;
+                    pgm_store_cell(cells_band + (size_t)t * 64u + lane, Mv, Xv, Wv, Yv);
                     W_left = Wv;
                     X_left = Xv;
                 }
                 {
                     const int ho = (int)((t & (H - 1)) << 6) + lane;
-                    hW[ho] = Wv; hY[ho] = Yv; hX[ho] = Xv;
+                    hW[(int)((t & (HW - 1)) << 6) + lane] = Wv;
+                    hY[ho] = Yv;
+                    hX[ho] = Xv;
                 }
                 W_diag = W_up;
                 W_o = Wv;
                 Y_o = Yv;
             }
-            // publish: everything but the youngest few vector-memory operations of this wavefront has
-            // completed, hence every cell store of the blocks before this one is visible to the CU.
+            // publish: the youngest BL vector-memory operations of this wavefront are this block's cell stores; once
+            // all older ones have retired, every (write-through) cell store of the blocks before this one is in memory.
             if (has_next) {
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
+                if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (has_next) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&prog[b], (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -434,7 +546,7 @@ __global__ void __launch_bounds__(256) pgm_emission_kernel(const PgmJob *__restr
         const float *tt = J.t2 + (size_t)J.dp * x;
         float acc = 0.0f;
         for (uint32_t k = 0; k < J.dim; ++k) acc = __fadd_rn(acc, __fmul_rn(g[k], tt[k]));
-        S[i] = pgm_emission_finish(acc, J.a1[y], J.aux2[2 * x].x, J.sc.match_init);
+        S[i] = pgm_emission_finish(acc, J.a1[y], J.b2[x], J.sc.match_init);
     }
 }
 
@@ -494,7 +606,7 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
     const float *tt = J.t2 + (size_t)J.dp * x;
     float acc = 0.0f;
     for (uint32_t k = 0; k < J.dim; ++k) acc = __fadd_rn(acc, __fmul_rn(g[k], tt[k]));
-    return pgm_emission_finish(acc, J.a1[y], J.aux2[2 * x].x, J.sc.match_init);
+    return pgm_emission_finish(acc, J.a1[y], J.b2[x], J.sc.match_init);
 }
 
 __global__ void __launch_bounds__(64) pgm_traceback_kernel(const PgmJob *__restrict__ jobs) {

@@ -66,11 +66,16 @@ struct pgm_align_batch {
     uint8_t *d_cells = nullptr;       // DP storage
     uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
     std::vector<uint8_t> h_out;
+    uint8_t *d_S = nullptr;           // emission scores in fill order
+    int *d_sync = nullptr;            // [0] abort flag, then the per-band progress counters of every job
+    size_t sync_ints = 0, s_bytes = 0;
+    PgmWorker *d_workers = nullptr;
+    uint32_t nworkers = 0, maxnblk = 0;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
     size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0, out_bytes = 0;
     std::vector<size_t> res_off, map1_off, map2_off;  // offsets inside d_out
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 extern "C" {
@@ -159,25 +164,23 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
         pp[v + 1] = (int32_t)pc.size();
         // summary of the extras for the on-chip (LDS history) path of the fill kernel
         const uint32_t nx = (uint32_t)(xp[v + 1] - xp[v]);
-        uint32_t dmax = 0;
-        bool generic = nx > 3;
-        for (uint32_t k = 0; k < nx; ++k) {
-            const uint32_t d = v - xc[xp[v] + k];
-            dmax = std::max(dmax, d);
-            if (d > 255) generic = true;
-        }
+        bool generic = nx > PGM_KX;
+        for (uint32_t k = 0; k < nx; ++k)
+            if (v - xc[xp[v] + k] > (uint32_t)(PGM_HIST - 1)) generic = true;
+        for (int k = 0; k < PGM_KX; ++k) { I.d[k] = 0; I.c[k] = INFINITY; }
         if (!generic) {
             I.flags = nx;
-            float *cs[3] = {&I.c1, &I.c2, &I.c3};
+            uint32_t dmax = 0;
             for (uint32_t k = 0; k < nx; ++k) {
-                I.dpack |= (v - xc[xp[v] + k]) << (8 * k);
-                *cs[k] = xv[xp[v] + k];
+                I.d[k] = (v - xc[xp[v] + k]) << 8;
+                I.c[k] = xv[xp[v] + k];
+                dmax = std::max(dmax, v - xc[xp[v] + k]);
             }
+            I.flags |= dmax << 8;
         } else {
-            I.flags = 4u;
+            I.flags = 8u;
         }
-        I.flags |= std::min(dmax, 255u) << 8;
-        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 8u;  // interior node without predecessors
+        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 16u;  // interior node without predecessors
     }
     // at least one element each so that pointers are valid
     if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
@@ -194,18 +197,6 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     return PGM_OK;
 }
 
-template <int DP, int NW>
-static hipError_t launch_fill(const pgm_align_batch *b, hipStream_t s) {
-    constexpr int NQ = DP / 4 + 2;
-    constexpr size_t wave_lds = (size_t)PGM_RING * NQ * 16 + 3 * PGM_HIST * 64 * 4 + PGM_BLOCK * PGM_HALO * 8;
-    const size_t lds = NW * wave_lds + (size_t)((b->maxnb + 3) / 4 * 4) * sizeof(int);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void *)pgm_fill_kernel<DP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pgm_fill_kernel<DP, NW>), dim3(b->njobs), dim3(NW * 64), lds, s, b->d_jobs, b->d_order);
-    return hipGetLastError();
-}
-
 static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipStream_t s = ctx->stream;
     hipError_t e;
@@ -214,13 +205,18 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipLaunchKernelGGL(pgm_prep_kernel, dim3(b->njobs, 2), dim3(256), prep_lds, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
-    if (b->maxdim <= 20) e = launch_fill<20, 6>(b, s);
-    else e = launch_fill<64, 4>(b, s);
-    if (e != hipSuccess) return e;
+    const dim3 eg((b->maxnblk + 3) / 4, b->maxnb, b->njobs);
+    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20>), eg, dim3(256), 0, s, b->d_jobs);
+    else hipLaunchKernelGGL((pgm_emission_skew_kernel<64>), eg, dim3(256), 0, s, b->d_jobs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(64), 0, s, b->d_jobs);
+    hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(64), 0, s, b->d_jobs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
 }
 }  // namespace
@@ -236,7 +232,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->njobs = njobs;
     b->jobs.resize(njobs);
     Arena A;
-    DevLayout W, C, O;
+    DevLayout W, C, O, SL;
+    size_t sync_ints = 4;   // [0] abort flag (+ padding to 16 B)
+    std::vector<size_t> prog_off(njobs), s_off(njobs);
     struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
@@ -253,6 +251,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.nb = (a->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
         J.ncol = c->n - 1;
         J.tsteps = J.ncol + 63;
+        J.nblk = (J.tsteps + PGM_BLOCK - 1) / PGM_BLOCK;
+        b->maxnblk = std::max(b->maxnblk, J.nblk);
         J.maxn = std::max(a->n, c->n);
         J.sc = scores[i];
         b->maxdim = std::max(b->maxdim, a->dim);
@@ -268,22 +268,28 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
         o.a1 = W.take(sizeof(float) * J.n1);
         o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
-        o.aux2 = W.take(sizeof(float4) * 2 * (size_t)J.n2);
+        o.aux2 = W.take(sizeof(float) * (size_t)J.n2);
         o.map1 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.map2 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.ms = W.take(4 * (size_t)J.maxn);
         o.mp = W.take(4 * (size_t)J.maxn);
         o.res = O.take(sizeof(PgmJob::Result), 16);
         o.cells = C.take(sizeof(float4) * (size_t)J.nb * J.tsteps * 64u, 1024);
+        s_off[i] = SL.take(sizeof(float) * (size_t)J.nb * J.nblk * 64u * PGM_BLOCK, 1024);
+        prog_off[i] = sync_ints;
+        sync_ints += (J.nb + 3) / 4 * 4;
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
     b->in_bytes = std::max<size_t>(A.host.size(), 16);
     b->work_bytes = std::max<size_t>(W.bytes, 16);
     b->cell_bytes = std::max<size_t>(C.bytes, 16);
     b->out_bytes = std::max<size_t>(O.bytes, 16);
+    b->s_bytes = std::max<size_t>(SL.bytes, 16);
+    b->sync_ints = sync_ints;
     hipError_t e;
     if ((e = hipMalloc((void **)&b->d_in, b->in_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_work, b->work_bytes)) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_out, b->out_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_out, b->out_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_S, b->s_bytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&b->d_sync, sync_ints * sizeof(int))) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(e == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -303,25 +309,73 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.pv1 = (const float *)(in + o.s1.pv); J.pv2 = (const float *)(in + o.s2.pv);
         J.pu1 = (const uint32_t *)(in + o.s1.pu); J.pu2 = (const uint32_t *)(in + o.s2.pu);
         J.g1f = (float *)(w + o.g1f); J.a1 = (float *)(w + o.a1);
-        J.t2 = (float *)(w + o.t2); J.aux2 = (float4 *)(w + o.aux2);
+        J.t2 = (float *)(w + o.t2); J.b2 = (float *)(w + o.aux2);
         J.map1 = (uint32_t *)(ob + o.map1); J.map2 = (uint32_t *)(ob + o.map2);
         J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
         J.result = (PgmJob::Result *)(ob + o.res);
         J.cells = (float4 *)(b->d_cells + o.cells);
+        J.S = (float *)(b->d_S + s_off[i]);
+        J.prog = b->d_sync + prog_off[i];
     }
     b->order.resize(njobs);
     std::iota(b->order.begin(), b->order.end(), 0u);
     std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) {
         return (uint64_t)b->jobs[x].n1 * b->jobs[x].n2 > (uint64_t)b->jobs[y].n1 * b->jobs[y].n2;
     });
+    // ---- fill workers: one wavefront each, all co-resident (4 per CU), shared out in proportion to the
+    // wave-steps of each job (largest job first so that its workers are dispatched first)
+    std::vector<PgmWorker> workers;
+    if (njobs) {
+        const uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 4u;
+        std::vector<double> ws(njobs);
+        double total = 0;
+        uint64_t bands = 0;
+        for (uint32_t i = 0; i < njobs; ++i) { ws[i] = (double)b->jobs[i].nb * b->jobs[i].tsteps; total += ws[i]; bands += b->jobs[i].nb; }
+        std::vector<uint32_t> wj(njobs, 1);
+        const uint32_t budget = (uint32_t)std::min<uint64_t>(capacity, bands);
+        if (budget > njobs) {
+            uint32_t used = 0;
+            for (uint32_t i = 0; i < njobs; ++i) {
+                uint32_t w = (uint32_t)(ws[i] / total * budget);
+                w = std::max(1u, std::min(w, b->jobs[i].nb));
+                wj[i] = w;
+                used += w;
+            }
+            // hand out what is left to the largest jobs first
+            for (uint32_t k = 0; used < budget && k < njobs; ++k) {
+                const uint32_t i = b->order[k];
+                if (wj[i] < b->jobs[i].nb) { ++wj[i]; ++used; }
+            }
+            while (used > budget) {   // rounding overshoot: take from the jobs with the most workers
+                uint32_t best = 0;
+                for (uint32_t i = 1; i < njobs; ++i) if (wj[i] > wj[best]) best = i;
+                if (wj[best] <= 1) break;
+                --wj[best]; --used;
+            }
+        } else if (budget < njobs) {
+            // more jobs than resident workers: every worker still owns whole jobs one after another is not supported
+            // by the persistent grid; run one worker per job and rely on the dispatcher (no inter-workgroup waits
+            // happen when a job has a single worker: band b-1 is always finished by the same wavefront).
+        }
+        for (uint32_t k = 0; k < njobs; ++k) {
+            const uint32_t i = b->order[k];
+            for (uint32_t r = 0; r < wj[i]; ++r) workers.push_back(PgmWorker{i, r, wj[i], 0});
+        }
+    }
+    b->nworkers = (uint32_t)workers.size();
+    if ((e = hipMalloc((void **)&b->d_workers, sizeof(PgmWorker) * std::max<size_t>(1, workers.size()))) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
     if ((e = hipMemcpyAsync(b->d_in, A.host.data(), A.host.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_workers, workers.data(), sizeof(PgmWorker) * workers.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
     }
-    for (int k = 0; k < 4; ++k) (void)hipEventCreate(&b->ev[k]);
+    for (int k = 0; k < 5; ++k) (void)hipEventCreate(&b->ev[k]);
     *out = b;
     return PGM_OK;
 }
@@ -334,22 +388,24 @@ int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b) {
     return PGM_OK;
 }
 
-int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep, float *ms_fill, float *ms_traceback) {
+int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep, float *ms_emission, float *ms_fill,
+                         float *ms_traceback) {
     if (!ctx || !b || reps <= 0) return fail(PGM_ERR_INVALID, "bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    double acc[3] = {0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps && b->njobs; ++r) {
         HIPCHK(launch_all(ctx, b, true));
-        HIPCHK(hipEventSynchronize(b->ev[3]));
-        for (int k = 0; k < 3; ++k) {
+        HIPCHK(hipEventSynchronize(b->ev[4]));
+        for (int k = 0; k < 4; ++k) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
             acc[k] += ms;
         }
     }
     if (ms_prep) *ms_prep = (float)(acc[0] / reps);
-    if (ms_fill) *ms_fill = (float)(acc[1] / reps);
-    if (ms_traceback) *ms_traceback = (float)(acc[2] / reps);
+    if (ms_emission) *ms_emission = (float)(acc[1] / reps);
+    if (ms_fill) *ms_fill = (float)(acc[2] / reps);
+    if (ms_traceback) *ms_traceback = (float)(acc[3] / reps);
     return PGM_OK;
 }
 
@@ -361,8 +417,11 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     // results + mappings live in one contiguous device region: a single D2H copy, then scatter
     int rc = PGM_OK;
     b->h_out.resize(b->out_bytes);
+    int aborted = 0;
     HIPCHK(hipMemcpyAsync(b->h_out.data(), b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&aborted, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out (workers not co-resident?)");
     for (uint32_t i = 0; i < b->njobs; ++i) {
         PgmJob::Result res;
         memcpy(&res, b->h_out.data() + b->res_off[i], sizeof res);
@@ -383,12 +442,15 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
 void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
     if (b->d_in) (void)hipFree(b->d_in);
     if (b->d_work) (void)hipFree(b->d_work);
     if (b->d_cells) (void)hipFree(b->d_cells);
     if (b->d_out) (void)hipFree(b->d_out);
+    if (b->d_S) (void)hipFree(b->d_S);
+    if (b->d_sync) (void)hipFree(b->d_sync);
+    if (b->d_workers) (void)hipFree(b->d_workers);
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_order) (void)hipFree(b->d_order);
     delete b;

@@ -8,23 +8,27 @@
 #define PGM_HALO 16        /* lanes 0..15 of a band replay the last 16 rows of the previous band */
 #define PGM_ROWS 48        /* rows computed per band = 64 lanes - PGM_HALO */
 #define PGM_BLOCK 16       /* steps between two synchronisation points of a band */
-#define PGM_HIST 16        /* steps of W/X/Y history kept in LDS per wavefront */
+#define PGM_HIST 32        /* steps of W/X/Y history kept in LDS per wavefront */
 #define PGM_RING 80        /* columns of T = M^T g2 kept in LDS per wavefront */
 
-// Per-node predecessor summary prepared by the host from the CSR (32 bytes).
+// Per-node predecessor summary prepared by the host from the CSR (64 bytes = 4 float4).
+//   q0 = {cc, flags, d0, d1}   q1 = {d2, d3, d4, d5}   q2 = {d6, c0, c1, c2}   q3 = {c3, c4, c5, c6}
 //   cc     cost of the chain edge (node-1 -> node), +inf if absent
-//   flags  bits 0-1: number n of other ("extra") predecessors when n <= 3
-//          bit 2   : generic — more than 3 extras or a distance > 255: use the CSR lists (xp/xc/xv)
-//          bit 3   : kill — interior node without any predecessor
-//          bits 8-15: largest distance (node - predecessor) among the extras, saturated at 255
-//   dpack  distances of the (up to 3) extras, 8 bits each;  c1..c3 their costs
+//   flags  bits 0-2: number n of other ("extra") predecessors served from the on-chip history (n <= 7)
+//          bits 8-15: largest distance among them
+//          bit 3   : generic — more than 7 extras or a distance > 31: every extra of this node is read from the
+//                    cell storage through the CSR lists (xp/xc/xv); then n = 0 and all d = 0, c = +inf
+//          bit 4   : kill — interior node without any predecessor
+//   d_k    (node - predecessor) << 8 of extra k, 0 if absent;   c_k its cost, +inf if absent (an absent
+//          extra therefore contributes -inf to every max without any masking)
+#define PGM_KX 7
 struct PgmNodeInfo {
     float cc;
     uint32_t flags;
-    uint32_t dpack;
-    float c1, c2, c3;
-    uint32_t pad0, pad1;
+    uint32_t d[PGM_KX];
+    float c[PGM_KX];
 };
+#define PGM_HISTW 32       /* steps of W history (pairs reach back dy+dx steps) */
 
 // One alignGraphs job, resident in HBM.  All pointers are device pointers.
 //
@@ -64,16 +68,29 @@ struct PgmJob {
     float *g1f;            // [n1][dp]  float(sites1), node-major, zero padded
     float *a1;             // [n1]      g1^T pi
     float *t2;             // [n2][dp]  T = M^T g2
-    float4 *aux2;          // [n2][2]   {pi^T g2, chain cost, flags, dpack} {c1, c2, c3, 0}  (PgmNodeInfo of the column)
+    float *b2;             // [n2]      pi^T g2
+
+    // emission scores produced by the emission kernel, in the order the fill kernel consumes them:
+    // S[((b * nblk + (t >> 4)) * 64 + lane) * 16 + (t & 15)] = S(y, x) of the cell lane `lane` of band b owns at step t
+    float *S;
+    uint32_t nblk;         // ceil(tsteps / 16)
 
     // DP storage
     float4 *cells;         // [nb][tsteps][64]
+    int *prog;             // [nb] steps of band b that are complete and visible device-wide (zeroed before every launch)
 
     // traceback output + scratch
     uint32_t *map1, *map2; // capacity n1+n2
     float *mark_score;     // [maxn]
     uint32_t *mark_prev;   // [maxn]
     struct Result { float score; uint32_t n_tr_indels; uint32_t len; int32_t status; } *result;
+};
+
+
+// One fill worker = one wavefront (a 64-thread workgroup).  Job `job` is swept by `nworkers` workers;
+// worker `rank` takes the bands rank, rank + nworkers, ...
+struct PgmWorker {
+    uint32_t job, rank, nworkers, pad;
 };
 
 #endif

@@ -156,9 +156,9 @@ class Batch:
         return self.cj.results()
 
     def time(self, reps):
-        a, b, c = C.c_float(), C.c_float(), C.c_float()
-        check(lib.pgm_align_batch_time(self.ctx.handle, self.handle, reps, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        a, e, b, c = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        check(lib.pgm_align_batch_time(self.ctx.handle, self.handle, reps, C.byref(a), C.byref(e), C.byref(b), C.byref(c)))
+        return a.value, e.value, b.value, c.value
 
     def read_matrices(self, job):
         j = self.cj.jobs[job]
