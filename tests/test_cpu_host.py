@@ -1,0 +1,96 @@
+"""CPU-only checks of the boundary and the host plumbing (no GPU compute calls)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    """include/pgm_hip.h is the drop-in boundary: every function it declares must be exported by libpgm_hip.so."""
+    import prographmsa_amd as pg
+    hdr = open(os.path.join(ROOT, "include", "pgm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(pgm_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    assert sorted(pg.EXPORTS) == declared, (sorted(pg.EXPORTS), declared)
+    for name in declared:
+        assert hasattr(pg.lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", pg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, out), "not an exported text symbol: " + name
+
+
+def test_struct_layouts_match_the_header():
+    import ctypes as C
+    import prographmsa_amd as pg
+    assert C.sizeof(pg.pgm_scores) == 40
+    assert C.sizeof(pg.pgm_graph) == 8 + 7 * 8
+    assert C.sizeof(pg.pgm_align_out) == 16 + 2 * 8
+    assert pg.pgm_align_out.map1.offset == 16
+
+
+def test_no_cpu_fallback_without_a_device():
+    """The product path fails loudly when no gfx950 device is present (no oracle / CPU fallback)."""
+    import prographmsa_amd as pg
+    if pg.lib.pgm_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pg.PgmError):
+        pg.Context(0)
+    r = subprocess.run([pg.PGMSA_PATH, "--fasta", "--tree", os.path.join(GOLD, "c1.tree"), os.path.join(GOLD, "c1.fa")],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot create a context" in r.stderr
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    import prographmsa_amd as pg
+    for path in (pg.LIB_PATH, pg.PGMSA_PATH):
+        out = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout
+        assert "pgmo_" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "prographmsa_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".inc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"import\s+oracle_lib|from\s+oracle_lib|pgmo_[a-z]|#include\s+\".*oracle|libpgm_oracle", txt), f
+
+
+def test_job_dump_roundtrip_and_oracle_invariants(oracle_build, tmp_path):
+    """pgmsa --dump_jobs -> jobs.load_jobs -> oracle: mappings are monotone, cover every node once, start/end right."""
+    import oracle_lib
+    from prographmsa_amd import jobs as J
+    dump = str(tmp_path / "jobs.bin")
+    subprocess.run([os.path.join(oracle_build, "pgmsa_oracle"), "--fasta", "--tree", os.path.join(GOLD, "c1.tree"),
+                    "--dump_jobs", dump, os.path.join(GOLD, "c1.fa")], check=True, capture_output=True)
+    js = J.load_jobs(dump)
+    assert len(js) == 7
+    for j in js:
+        r = oracle_lib.align_graphs(j)
+        m1, m2 = r["map1"], r["map2"]
+        assert r["status"] == 0 and len(m1) == len(m2)
+        assert (m1[0], m2[0]) == (0, 0) and (m1[-1], m2[-1]) == (j.g1.n - 1, j.g2.n - 1)
+        for m in (m1, m2):
+            v = m[m != 0xFFFFFFFF].astype(np.int64)
+            assert np.all(np.diff(v) > 0)
+        assert not np.any((m1 == 0xFFFFFFFF) & (m2 == 0xFFFFFFFF))
+
+
+def test_random_job_generator_is_deterministic():
+    from prographmsa_amd import jobs as J
+    a, b = J.random_job(5, 30, 40, skip_frac=0.3, repeat_frac=0.1), J.random_job(5, 30, 40, skip_frac=0.3, repeat_frac=0.1)
+    assert np.array_equal(a.g1.e_col, b.g1.e_col) and np.array_equal(a.g2.sites, b.g2.sites)
+    assert a.g1.r_col is not None or a.g2.r_col is not None
+
+
+def test_workqueue_partitions():
+    from prographmsa_amd import workqueue as wq
+    lengths = [5, 9, 2, 7, 7, 3, 11]
+    n = len(wq.all_pairs(len(lengths)))
+    for world in (1, 2, 3, 8):
+        seen = sorted(p for r in range(world) for p in wq.shard_pairs(lengths, r, world))
+        assert seen == list(range(n))
+        spans = [wq.shard_range(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
