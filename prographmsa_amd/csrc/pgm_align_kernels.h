@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
 
         // ---- data of the next block, in flight while the current block is computed -----------------
         float4 pfq[PFQ];           // column summaries [c0, c0+16)
-        float2 pfr[4];             // replay tile
+        constexpr int PFR = BL * HR / 64;   // replay-tile elements per lane
+        static_assert(BL * HR % 64 == 0, "replay tile must divide evenly over the lanes");
+        float2 pfr[PFR];           // replay tile
         float4 pfs[BL / 4];        // emission scores of this lane
         auto load_ring_block = [&](uint32_t c0) {
 #pragma unroll
@@ -307,13 +309,13 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 if (idx < BL * NQ) ring[(col % R) * NQ + (idx % NQ)] = pfq[u];
             }
         };
-        // replay tile of the 16 steps starting at s0: element e = i*16 + l -> {W,Y} of band b-1, step s0+i+48, lane 48+l
+        // replay tile of the BL steps starting at s0: element e = i*16 + l -> {W,Y} of band b-1, step s0+i+48, lane 48+l
         auto load_rep_block = [&](uint32_t s0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = lane * 4 + u;
-                const uint32_t st = s0 + (uint32_t)(e >> 4) + (uint32_t)RC;
-                const int l = e & 15;
+            for (int u = 0; u < PFR; ++u) {
+                const int e = lane * PFR + u;
+                const uint32_t st = s0 + (uint32_t)(e / HR) + (uint32_t)RC;
+                const int l = e % HR;
                 float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
                 if (has_prev && st < tsteps) v = pgm_load_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
                 pfr[u] = v;
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
         };
         auto store_rep_block = [&]() {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rep[lane * 4 + u] = pfr[u];
+            for (int u = 0; u < PFR; ++u) rep[lane * PFR + u] = pfr[u];
         };
         auto load_s_block = [&](uint32_t s0) {
             const uint32_t tb = s0 / BL;

@@ -7,7 +7,7 @@
 
 #define PGM_HALO 16        /* lanes 0..15 of a band replay the last 16 rows of the previous band */
 #define PGM_ROWS 48        /* rows computed per band = 64 lanes - PGM_HALO */
-#define PGM_BLOCK 16       /* steps between two synchronisation points of a band */
+#define PGM_BLOCK 8        /* steps between two synchronisation points of a band */
 #define PGM_HIST 32        /* steps of W/X/Y history kept in LDS per wavefront */
 #define PGM_RING 80        /* columns of T = M^T g2 kept in LDS per wavefront */
 
