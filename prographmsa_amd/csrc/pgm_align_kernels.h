@@ -603,18 +603,47 @@ __device__ static void pgm_mark_alternative_path(const PgmJob &J, uint32_t start
     }
 }
 
+// S(y,x) as the emission kernel stored it (skewed order, see PgmJob::S): one load instead of recomputing the dot product
 __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, uint32_t x) {
-    const float *g = J.g1f + (size_t)J.dp * y;
-    const float *tt = J.t2 + (size_t)J.dp * x;
-    float acc = 0.0f;
-    for (uint32_t k = 0; k < J.dim; ++k) acc = __fadd_rn(acc, __fmul_rn(g[k], tt[k]));
-    return pgm_emission_finish(acc, J.a1[y], J.b2[x], J.sc.match_init);
+    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS), t = x + l;
+    return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
 }
 
-__global__ void __launch_bounds__(64) pgm_traceback_kernel(const PgmJob *__restrict__ jobs) {
+// Workgroup = 2 wavefronts: wavefront 0 walks (lane 0), wavefront 1 runs ahead of it and touches the cells of the
+// next PGM_TB_AHEAD anti-diagonals the walk can reach, so that the walker's dependent loads hit L2 instead of HBM
+// (the walk is a pointer chase: one cell decides which cell is read next).
+#define PGM_TB_AHEAD 48
+__global__ void __launch_bounds__(128) pgm_traceback_kernel(const PgmJob *__restrict__ jobs) {
     const PgmJob &J = jobs[blockIdx.x];
     const int lane = threadIdx.x;
     __shared__ uint32_t s_len;
+    __shared__ int s_pos[2];
+    __shared__ int s_done;
+    if (threadIdx.x == 0) { s_pos[0] = (int)J.n1 - 2; s_pos[1] = (int)J.n2 - 2; s_done = 0; }
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+        // ---- prefetcher wavefront ----
+        const int l = threadIdx.x - 64;
+        int lowest = (int)(J.n1 + J.n2);   // diagonals >= lowest have been touched
+        uint32_t sink = 0;
+        while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+            const int y = __hip_atomic_load(&s_pos[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int x = __hip_atomic_load(&s_pos[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int d = y + x;
+            const int target = max(d - PGM_TB_AHEAD, 0);
+            if (lowest > d + 1) lowest = d + 1;
+            if (lowest <= target) { __builtin_amdgcn_s_sleep(8); continue; }
+            for (int dd = lowest - 1; dd >= target; --dd) {
+                // cells (yy, dd - yy) reachable from (y, x): yy <= y, dd - yy <= x
+                const int yy = min(y, dd) - l;
+                const int xx = dd - yy;
+                if (yy >= 0 && xx >= 0 && xx <= x && yy <= (int)J.n1 - 2 && xx <= (int)J.n2 - 2)
+                    sink += __float_as_uint(J.cells[pgm_cell_index(J, (uint32_t)yy, (uint32_t)xx)].x);
+            }
+            lowest = target;
+        }
+        if (sink == 0x7fc12345u) J.mark_prev[0] = sink;   // keeps the loads alive; never true for real scores
+    }
     if (lane == 0) {
         const pgm_scores s = J.sc;
         const uint32_t n1 = J.n1, n2 = J.n2;
@@ -679,6 +708,8 @@ __global__ void __launch_bounds__(64) pgm_traceback_kernel(const PgmJob *__restr
         uint32_t guard = 0;
         while ((x != 0 || y != 0) && status == PGM_OK) {
             if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
+            __hip_atomic_store(&s_pos[0], (int)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_pos[1], (int)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             best = INFINITY;
             // choose the state of a W source by equality, order M, Y, X (GraphAlign.h:400-411)
 #define PGM_PICK(cell)                                                                        \
@@ -741,12 +772,13 @@ __global__ void __launch_bounds__(64) pgm_traceback_kernel(const PgmJob *__restr
         J.result->len = mo.len;
         J.result->status = status;
         s_len = mo.len;
+        __hip_atomic_store(&s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
-    // reverse the two mappings in place (GraphAlign.h:520-521), all 64 lanes
+    // reverse the two mappings in place (GraphAlign.h:520-521), all 128 threads
     const uint32_t len = s_len;
     __threadfence_block();
-    for (uint32_t i = lane; i < len / 2; i += 64) {
+    for (uint32_t i = lane; i < len / 2; i += 128) {
         const uint32_t j = len - 1 - i;
         uint32_t a = J.map1[i], b2 = J.map1[j];
         J.map1[i] = b2; J.map1[j] = a;

@@ -217,7 +217,7 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(64), 0, s, b->d_jobs);
+    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
