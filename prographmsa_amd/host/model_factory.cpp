@@ -1,10 +1,10 @@
 // model_factory.cpp — substitution models (reference src/ModelFactory.{h,cpp},
 // ModelFactoryWag.cpp:17-441, ModelFactoryEcm.cpp:20-3763).
 //
-// The reference sets up Q with Eigen's general (non-symmetric) EigenSolver.  WAG and ECM are
-// time-reversible, so here Q is symmetrised with pi^(1/2) and diagonalised with cyclic Jacobi;
-// P(t) = V exp(sigma t) V^-1 agrees with the reference's to ~1e-15 (double), far below the
-// float cast applied before it reaches the DP.
+// The reference sets up Q with Eigen's general (non-symmetric) EigenSolver and evaluates
+// P(t) = V exp(sigma t) V^-1.  Here: a symmetrised Jacobi eigen-decomposition when the generator is reversible
+// to rounding error (WAG), a scaling-and-squaring matrix exponential otherwise (ECM); both agree with the
+// reference to ~1e-14 (double), far below the float cast applied before P reaches the DP.
 #include "pgm_host.h"
 
 #include <algorithm>
@@ -79,6 +79,45 @@ static std::vector<double> jacobi(std::vector<double> A, std::vector<double> &U,
     return ev;
 }
 
+// C = A * B (n x n, column-major)
+static void matmul(const std::vector<double> &A, const std::vector<double> &B, int n, std::vector<double> &C) {
+    C.assign((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+            const double b = B[k + n * j];
+            if (b == 0) continue;
+            const double *a = &A[(size_t)n * k];
+            double *c = &C[(size_t)n * j];
+            for (int i = 0; i < n; ++i) c[i] += a[i] * b;
+        }
+}
+
+// exp(A) by scaling and squaring with a Taylor series (||A/2^s||_1 <= 1/2, 20 terms: truncation < 1e-20).
+// The reference evaluates P(d) = V exp(sigma d) V^-1 from Eigen's non-symmetric EigenSolver; both are exp(Q d) to
+// ~1e-14, far below the float cast applied before P reaches the DP, and this form needs no reversibility assumption
+// (the ECM data is reversible only to ~1e-6).
+static std::vector<double> expm(std::vector<double> A, int n) {
+    double norm = 0;
+    for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += std::fabs(A[i + n * j]);
+        norm = std::max(norm, s);
+    }
+    int sq = 0;
+    while (norm > 0.5) { norm *= 0.5; ++sq; }
+    const double scale = std::ldexp(1.0, -sq);
+    for (double &a : A) a *= scale;
+    std::vector<double> E((size_t)n * n, 0.0), term((size_t)n * n, 0.0), tmp;
+    for (int i = 0; i < n; ++i) { E[i + n * i] = 1.0; term[i + n * i] = 1.0; }
+    for (int k = 1; k <= 20; ++k) {
+        matmul(term, A, n, tmp);
+        const double inv = 1.0 / k;
+        for (size_t i = 0; i < tmp.size(); ++i) { term[i] = tmp[i] * inv; E[i] += term[i]; }
+    }
+    for (int k = 0; k < sq; ++k) { matmul(E, E, n, tmp); E.swap(tmp); }
+    return E;
+}
+
 ModelFactory::ModelFactory(int dim, const std::string &qmat_file) : dim_(dim) {
     const int n = dim;
     std::ifstream in(qmat_file.c_str());
@@ -134,7 +173,10 @@ ModelFactory::ModelFactory(int dim, const std::string &qmat_file) : dim_(dim) {
             double m = 0.5 * (B[i + n * j] + B[j + n * i]);
             B[i + n * j] = B[j + n * i] = m;
         }
-    if (asym > 1e-9 * std::max(scale, 1.0)) error("rate matrix is not reversible (asymmetry %g); a general eigen-solver would be needed", asym);
+    // WAG is reversible to rounding error; the ECM data only to ~1e-6: then P(d) = exp(Q d) is evaluated with a
+    // scaling-and-squaring matrix exponential instead (no reversibility assumed), see fillP.
+    use_eigen_ = asym <= 1e-9 * std::max(scale, 1.0);
+    if (!use_eigen_) return;
     sigma_ = jacobi(B, U, n);
     V_.resize((size_t)n * n);
     Vi_.resize((size_t)n * n);
@@ -174,16 +216,22 @@ void ModelFactory::parseDistance(distance_t distance, Model &model) {
 void ModelFactory::fillP(Model &model) const {
     const int n = dim_;
     model.dim = n;
-    std::vector<double> e(n), tmp((size_t)n * n);
-    for (int k = 0; k < n; ++k) e[k] = std::exp(sigma_[k] * model.distance);
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < n; ++k) tmp[i + n * k] = V_[i + n * k] * e[k];
-    model.P.assign((size_t)n * n, 0.0);
-    for (int j = 0; j < n; ++j)
-        for (int k = 0; k < n; ++k) {
-            double v = Vi_[k + n * j];
-            for (int i = 0; i < n; ++i) model.P[i + n * j] += tmp[i + n * k] * v;
-        }
+    if (use_eigen_) {
+        std::vector<double> e(n), tmp((size_t)n * n);
+        for (int k = 0; k < n; ++k) e[k] = std::exp(sigma_[k] * model.distance);
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < n; ++k) tmp[i + n * k] = V_[i + n * k] * e[k];
+        model.P.assign((size_t)n * n, 0.0);
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < n; ++k) {
+                const double v = Vi_[k + n * j];
+                for (int i = 0; i < n; ++i) model.P[i + n * j] += tmp[i + n * k] * v;
+            }
+    } else {
+        std::vector<double> A(Q_);
+        for (double &a : A) a *= model.distance;
+        model.P = expm(A, n);
+    }
     model.M.resize((size_t)n * n);
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) model.M[i + n * j] = freqs_[i] * model.P[i + n * j];

@@ -91,8 +91,8 @@ struct Model {
 };
 
 // ModelFactory (ModelFactory.h:11-34) with the WAG (ModelFactoryWag.cpp) and ECM
-// (ModelFactoryEcm.cpp) rate matrices.  The eigen-decomposition uses the reversibility of the
-// models (symmetrised Jacobi) instead of Eigen's general EigenSolver; P(t) agrees to ~1e-15.
+// (ModelFactoryEcm.cpp) rate matrices.  P(t) = exp(Q t) by scaling-and-squaring instead of Eigen's
+// general EigenSolver; agrees to ~1e-14.
 class ModelFactory {
 public:
     static ModelFactory *getDefault(const Alphabet &a);          // ModelFactory.cpp:11-36
@@ -110,6 +110,7 @@ private:
     void fillP(Model &model) const;
     int dim_;
     std::vector<double> freqs_, Q_, V_, Vi_, sigma_;
+    bool use_eigen_ = false;
 };
 
 // ---------------------------------------------------------------------------------------

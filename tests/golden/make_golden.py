@@ -89,6 +89,21 @@ def main():
     w("K50.lib", gen.genlib(50, 7))
     w("c1.cs.out.fa", run(["--fasta", "--tree", "c1.tree", "--cs_profile", "K50.lib", "c1.fa"]))
     w("c1.cs_ml.out.fa", run(["--fasta", "-m", "--tree", "c1.tree", "--cs_profile", "K50.lib", "c1.fa"]))
+    # codon mode (61-state ECM model, BASELINE config 4 in small): in-frame sense codons
+    w("cd1.fa", gen.fasta(gen.gen_codon(6, 60, 21, sub=0.06, indel=0.01)))
+    w("cd1.tree", run(["--codon", "-T", "-i", "0", "cd1.fa"]))
+    w("cd1.out.fa", run(["--codon", "--fasta", "-t", "cd1.tree", "cd1.fa"]))
+    w("cd2.fa", gen.fasta(gen.gen_codon(16, 150, 22, sub=0.05, indel=0.008)))
+    w("cd2.tree", run(["--codon", "-T", "-i", "0", "cd2.fa"]))
+    w("cd2.out.fa", run(["--codon", "--fasta", "-t", "cd2.tree", "cd2.fa"]))
+    # codon alignPair + ML distance, 2 sequences each (a 6-taxon BioNJ tree would end in the exact 4-taxon NJ tie again)
+    cnw = {}
+    for seed in range(300, 306):
+        s = gen.gen_codon(2, 70, seed, sub=0.1, indel=0.02)
+        fa = ">a\n%s\n>b\n%s\n" % (s[0], s[1])
+        w("pair.fa.tmp", fa)
+        cnw[str(seed)] = dict(fasta=fa, ml=run(["--codon", "-a", "-m", "-T", "-i", "0", "pair.fa.tmp"]))
+    w("nw_pairs_codon.json", json.dumps(cnw, indent=0))
     w("md5.json", json.dumps(md5, indent=1))
     for f in ("c3.fa.tmp", "pair.fa.tmp", "pair.tree.tmp"):
         os.remove(f)

@@ -80,3 +80,17 @@ def test_c3_256x1000_md5(oracle_build, tmp_path):
     (tmp_path / "c3.fa").write_text(fa)
     out = run_oracle(oracle_build, ["--fasta", "-m", "-t", os.path.join(GOLD, "c3.tree"), str(tmp_path / "c3.fa")])
     assert hashlib.md5(out.encode()).hexdigest() == md5["c3.out.fa"]
+
+
+@pytest.mark.parametrize("case", ["cd1", "cd2"])
+def test_codon_fasta_identical_to_reference(oracle_build, case):
+    """--codon: 61-state ECM model, codon alphabet (BASELINE config 4 in small)."""
+    out = run_oracle(oracle_build, ["--codon", "--fasta", "-t", os.path.join(GOLD, case + ".tree"), os.path.join(GOLD, case + ".fa")])
+    assert out == gold(case + ".out.fa")
+
+
+def test_codon_nw_distance_pairs(oracle_build, tmp_path):
+    nw = json.load(open(os.path.join(GOLD, "nw_pairs_codon.json")))
+    for seed, p in nw.items():
+        (tmp_path / "p.fa").write_text(p["fasta"])
+        assert run_oracle(oracle_build, ["--codon", "-a", "-m", "-T", "-i", "0", str(tmp_path / "p.fa")]) == p["ml"], seed
