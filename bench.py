@@ -114,6 +114,44 @@ def main():
                 "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill": round(ms_fill, 4), "traceback": round(ms_tb, 4)},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
 
+    # ---- all-pairs stage (DistanceFactoryAlign, `-a`): the 32 640 alignPair jobs of the same family, sharded over the
+    # ranks (strong scaling of this stage: no collective, rank 0 would gather counts/gaps) --------------------------------
+    import ctypes as C
+    from prographmsa_amd import workqueue as wq
+    seqs_aa = gen.gen(args.nseq, args.len, 3)
+    order = "ACDEFGHIKLMNPQRSTVWY"
+    enc = [np.array([order.index(c) for c in s[1:] if True] if s.startswith("M") else [order.index(c) for c in s], np.int8) for s in seqs_aa]
+    lens = [len(e) for e in enc]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    syms = np.concatenate(enc).astype(np.int8)
+    pairs = wq.all_pairs(len(enc))
+    mine = wq.shard_pairs(lens, rank, world)
+    pi = np.array([pairs[p][0] for p in mine], np.uint32)
+    pj = np.array([pairs[p][1] for p in mine], np.uint32)
+    score = np.loadtxt(os.path.join(ROOT, "prographmsa_amd", "host", "data", "nw_aa.imat"), skiprows=1, dtype=np.int32).reshape(-1)
+    counts = np.zeros(len(mine) * 400, np.int32)
+    gaps = np.zeros(len(mine), np.uint32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    nw_cells = float(sum(lens[pairs[p][0]] * lens[pairs[p][1]] for p in mine))
+
+    def nw_call():
+        pg.check(pg.lib.pgm_nw_pairs_batch(ctx.handle, 20, P(score, C.c_int32), -10, -2, len(enc), P(syms, C.c_int8), P(offs, C.c_uint32),
+                                           len(mine), P(pi, C.c_uint32), P(pj, C.c_uint32), P(counts, C.c_int32), P(gaps, C.c_uint32)))
+    nw_call()
+    barrier()
+    t0 = time.perf_counter()
+    nw_call()
+    barrier()
+    nw_dt = time.perf_counter() - t0
+    nw_kernel_ms = float(pg.lib.pgm_nw_last_kernel_ms(ctx.handle))
+    nw_total = nw_cells
+    if world > 1:
+        t = torch.tensor([nw_dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c = torch.tensor([nw_cells], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        nw_dt, nw_total = float(t.item()), float(c.item())
+
     out = None
     if rank == 0:
         out = {
@@ -126,6 +164,11 @@ def main():
                                    "(%.3e DP cells) per GPU, inputs resident in HBM" % (args.nseq, args.len, len(jobs), cells),
                        "headline": headline, "device": devname, "cus": cus, "jobs": len(jobs), "cells_per_step": cells},
             "roofline": roofline,
+            "all_pairs_nw": {"pairs_total": len(pairs), "cells_total": nw_total, "wall_s": round(nw_dt, 4),
+                             "gcups_wall": round(nw_total / nw_dt / 1e9, 2), "rank0_kernel_ms": round(nw_kernel_ms, 3),
+                             "rank0_kernel_gcups": round(nw_cells / (nw_kernel_ms * 1e-3) / 1e9, 2), "scaling": "strong",
+                             "note": "whole pgm_nw_pairs_batch call incl. H2D of sequences and D2H of the 400-int count matrices; "
+                                     "2 direction bits/cell stored (reference formulation: 12 B/cell)"},
             "end_to_end": {"pgmsa_wall_s": round(e2e_wall, 3), "progressive_s": stats["progressive_s"],
                            "align_call_s": stats["align_s"], "note": "untimed set-up run of the product driver incl. host merges, H2D/D2H and hipMalloc"},
         }
