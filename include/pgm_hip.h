@@ -111,7 +111,9 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);
 uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
 /* Run the batch `reps` times back to back and return the mean device time in milliseconds of
  * each kernel stage (prep, emission scores, DP fill, traceback), measured with HIP events on
- * the context's stream. */
+ * the context's stream.  The traceback kernel runs on a second stream concurrently with the fill
+ * (each job is walked as soon as its last band is complete); ms_traceback is the tail that is
+ * left after the fill kernel has ended. */
 int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
                          float *ms_emission, float *ms_fill, float *ms_traceback);
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,

@@ -530,10 +530,9 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (has_next) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // band complete (the last band's counter is what the concurrently launched traceback workgroup of this job waits for)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -613,14 +612,34 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 // next PGM_TB_AHEAD anti-diagonals the walk can reach, so that the walker's dependent loads hit L2 instead of HBM
 // (the walk is a pointer chase: one cell decides which cell is read next).
 #define PGM_TB_AHEAD 48
-__global__ void __launch_bounds__(128) pgm_traceback_kernel(const PgmJob *__restrict__ jobs) {
+__global__ void __launch_bounds__(128) pgm_traceback_kernel(const PgmJob *__restrict__ jobs, int *__restrict__ abort_flag) {
     const PgmJob &J = jobs[blockIdx.x];
     const int lane = threadIdx.x;
+    __shared__ int s_abort;
     __shared__ uint32_t s_len;
     __shared__ int s_pos[2];
     __shared__ int s_done;
-    if (threadIdx.x == 0) { s_pos[0] = (int)J.n1 - 2; s_pos[1] = (int)J.n2 - 2; s_done = 0; }
+    if (threadIdx.x == 0) {
+        s_pos[0] = (int)J.n1 - 2; s_pos[1] = (int)J.n2 - 2; s_done = 0;
+        // This kernel runs on a second stream concurrently with the fill kernel: wait until the job's last band is complete
+        // (its cells are written through to memory before the counter is set; nothing of them is cached on this CU yet).
+        uint32_t spins = 0;
+        int ab = 0;
+        while (__hip_atomic_load(&J.prog[J.nb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0x7fffffff) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ab = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_abort = ab;
+    }
     __syncthreads();
+    if (s_abort) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE;
+        }
+        return;
+    }
     if (threadIdx.x >= 64) {
         // ---- prefetcher wavefront ----
         const int l = threadIdx.x - 64;

@@ -28,6 +28,8 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 struct pgm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // traceback runs here, concurrently with the fill kernel
+    hipEvent_t ev_ready = nullptr, ev_tb = nullptr;
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0;
     // context-profile library resident in HBM
@@ -99,6 +101,9 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     c->device = device;
     HIPCHK(hipGetDeviceProperties(&c->prop, device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_tb, hipEventDisableTiming));
     *out = c;
     return PGM_OK;
 }
@@ -110,6 +115,9 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+    if (ctx->ev_tb) (void)hipEventDestroy(ctx->ev_tb);
     delete ctx;
 }
 
@@ -214,11 +222,17 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
+    // The traceback workgroups are launched on a second stream and start as soon as their job's last band is published,
+    // so the walks of all small jobs overlap the fill of the large ones.
+    if ((e = hipEventRecord(ctx->ev_ready, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, s, b->d_jobs);
+    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, ctx->stream2, b->d_jobs, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ctx->ev_tb, ctx->stream2)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, ctx->ev_tb, 0)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
 }
