@@ -182,14 +182,21 @@ __device__ __forceinline__ int pgm_wave_max8(uint32_t v) {
 // device-wide (agent scope) accesses to the DP storage: a band may be continued on another CU / XCD, whose L1
 // never sees our stores and whose L2 is not coherent with ours, so cells are written through (sc1) and read
 // with L1-bypassing loads; the hand-off itself is the progress counter below (MI355X guide, Guideline 16 R1).
-__device__ __forceinline__ void pgm_store_cell(float4 *p, float Mv, float Xv, float Wv, float Yv) {
-    // one 16-byte write-through store (sc1 = device scope): `global_store_dwordx4 ... sc1`.  hipcc does not count
-    // inline-asm memory operations in its own s_waitcnt bookkeeping; an uncounted extra store only makes the
-    // compiler's counted waits stricter (vmcnt retires in issue order), never weaker.
-    typedef float pgm_v4f __attribute__((ext_vector_type(4)));
-    pgm_v4f v;
-    v.x = Mv; v.y = Xv; v.z = Wv; v.w = Yv;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+// The cell store is a raw buffer store with aux = 16 (sc1, write-through to device scope): unlike an inline-asm
+// store it is counted by hipcc's s_waitcnt bookkeeping, so the counted waits on the prefetch loads stay exact.
+// The descriptor covers one band (tsteps * 64 cells); the step offset goes in the scalar offset, the lane in voffset.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pgm_band_rsrc(float4 *base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+template <int MODE = 0>
+__device__ __forceinline__ void pgm_store_cell(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, float Mv, float Xv, float Wv, float Yv) {
+    typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
+    pgm_v4u v;
+    v.x = __float_as_uint(Mv); v.y = __float_as_uint(Xv); v.z = __float_as_uint(Wv); v.w = __float_as_uint(Yv);
+    if (MODE == 1) return;                                                    // timing experiments only
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane(t) * 1024u, MODE == 2 ? 0 : 16);
 }
 __device__ __forceinline__ float2 pgm_load_cell_mx(const float4 *p) {   // {M, X}
     const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -273,6 +280,7 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
         const bool has_next = (b + 1 < nb);
         const bool has_prev = (b > 0);
         float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
+        const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
         const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;  // only dereferenced if has_prev
         const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
         const float4 *ni2q = (const float4 *)J.ni2;
@@ -343,11 +351,14 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 sblk[(4 * q + 3) * 64 + lane] = pfs[q].w;
             }
         };
+        int seen = has_prev ? 0 : 0x7fffffff, pend = 0;   // progress of band b-1: last value seen / value in flight
         auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
-            if (has_prev && !aborted) {
+            if (seen != 0x7fffffff && !aborted) {
                 const int need = (int)min(steps_needed, tsteps);
                 uint32_t spins = 0;
-                while (__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                while (seen < need) {
+                    seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen >= need) break;
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                         __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,6 +368,10 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 }
             }
         };
+        // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
+        // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
+        auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
 
         // prologue: data of block 0 straight in, data of block 1 in flight
         load_ring_block(0);
@@ -369,8 +384,12 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
         load_ring_block(BL);
         load_s_block(BL);
         load_rep_block(BL);
+        poll_issue();
 
+        unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0, cyc_w = 0;
         for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
+            const unsigned long long c0 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
+            unsigned long long cw0 = 0, cw1 = 0;
             if (t0 > 0) {
                 // data loaded during the previous block becomes current; start loading the next block
                 store_ring_block(t0);
@@ -378,9 +397,14 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 store_s_block();
                 load_ring_block(t0 + BL);
                 load_s_block(t0 + BL);
-                wait_prev(t0 + BL + BL + RC);   // replay tile of block t0+16 reads steps < t0+16+16+48 of band b-1
+                poll_collect();
+                if (DUMMY == 4) cw0 = __builtin_readcyclecounter();
+                wait_prev(t0 + BL + BL + RC);   // replay tile of block t0+BL reads steps < t0+2BL+48 of band b-1
+                if (DUMMY == 4) cw1 = __builtin_readcyclecounter();
                 load_rep_block(t0 + BL);
+                poll_issue();
             }
+            const unsigned long long c1 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll 1
             for (int i = 0; i < BL; ++i) {
                 const uint32_t t = t0 + i;
@@ -509,7 +533,7 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                     Yv = incol ? rv.y : PGM_NEG_INF;
                 }
                 if (active) {
-                    pgm_store_cell(cells_band + (size_t)t * 64u + lane, Mv, Xv, Wv, Yv);
+                    pgm_store_cell<DUMMY>(cells_rsrc, t, lane, Mv, Xv, Wv, Yv);
                     W_left = Wv;
                     X_left = Xv;
                 }
@@ -523,16 +547,440 @@ __global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__
                 W_o = Wv;
                 Y_o = Yv;
             }
+            const unsigned long long c2 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
             // publish: the youngest BL vector-memory operations of this wavefront are this block's cell stores; once
             // all older ones have retired, every (write-through) cell store of the blocks before this one is in memory.
             if (has_next) {
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
                 if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (DUMMY == 4) { const unsigned long long c3 = __builtin_readcyclecounter(); cyc_a += c1 - c0; cyc_b += c2 - c1; cyc_c += c3 - c2; cyc_w += cw1 - cw0; }
+        }
+        if (DUMMY == 4 && lane == 0) {
+            const uint32_t nblocks = tsteps / BL;
+            J.map1[4 * b + 0] = (uint32_t)(cyc_a / nblocks); J.map1[4 * b + 1] = (uint32_t)(cyc_w / nblocks);
+            J.map1[4 * b + 2] = (uint32_t)(cyc_b / nblocks); J.map1[4 * b + 3] = (uint32_t)(cyc_c / nblocks);
         }
         // band complete (the last band's counter is what the concurrently launched traceback workgroup of this job waits for)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fill kernel with helper wavefronts (used when a batch contains merged graphs, i.e. skip-edge predecessors).
+//
+// Same band sweep as pgm_fill_kernel, but a worker is a 256-thread workgroup: wavefront 0 ("main") owns the band's
+// dependency chain (chain predecessors, cell store, history, hand-off to the next band); wavefronts 1..3 ("helpers")
+// evaluate the skip-edge terms.  This works because every skip-edge term of step t only needs history up to step
+// t-2 (an extra predecessor is at least 2 nodes back): the helpers compute the terms of step t while the main
+// wavefront is still finishing steps t-2 and t-1, so the ~300 instructions of the skip-edge path leave the band's
+// critical path and the main wavefront's step shrinks to the chain recurrence plus five LDS reads.
+//   helper 1: column extras (X terms, M terms with the chain row)
+//   helper 2: row extras (Y terms, M terms with the chain column) and the pairs of the first row extra
+//   helper 3: the pairs of the other row extras
+// Hand-shake through LDS counters (workgroup-scope release/acquire): main_done = last step whose history is written,
+// help_done[h] = last step whose partial maxima are in `res`.  res has four step slots; the ring of column summaries
+// and the emission scores are stored one block earlier than in the single-wavefront kernel (helpers run up to two
+// steps ahead of the main wavefront), so they are loaded two blocks ahead and the scores are double buffered.
+template <int DUMMY>
+__global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict__ jobs, const PgmWorker *__restrict__ workers,
+                                                       int *__restrict__ abort_flag) {
+    constexpr int NQ = 4;
+    constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
+    constexpr int PFQ = (BL * NQ + 63) / 64;
+    constexpr int NH = 3;
+    __shared__ __attribute__((aligned(16))) float4 ring[R * NQ];
+    __shared__ float hW[HW * 64];
+    __shared__ float hY[H * 64];
+    __shared__ float hX[H * 64];
+    __shared__ float2 rep[BL * HR];
+    __shared__ float sblk[2 * BL * 64];
+    __shared__ float res[4 * 5 * 64];      // [step & 3][field][lane]; fields: H1.M, H1.X, H2.M, H2.Y, H3.M
+    __shared__ int main_done, help_done[NH], lds_abort;
+
+    const PgmWorker wk = workers[blockIdx.x];
+    const PgmJob &J = jobs[wk.job];
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
+    const bool need_help = J.has_extras != 0;
+    if (role != 0 && !need_help) return;     // chain-only job: the main wavefront alone (no barriers are used then)
+    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
+    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
+    bool aborted = false;
+    if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (uint32_t b = wk.rank; b < nb && !aborted; b += wk.nworkers) {
+        const bool comp = lane >= HR;
+        const uint32_t y = RC * b + (uint32_t)(lane - HR);
+        const bool rowvalid = comp && y + 1 < n1;
+        const uint32_t yc = rowvalid ? y : 0u;
+        const PgmNodeInfo niy = J.ni1[yc];
+        const float ccy = niy.cc;
+        const uint32_t fy = rowvalid ? niy.flags : 0u;
+        const uint32_t dymax = (fy >> 8) & 255u;
+        const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
+        const bool ykill = (fy & 16u) != 0;
+        uint32_t rk8[PGM_KX], lk4[PGM_KX];
+        float cyv[PGM_KX];
+#pragma unroll
+        for (int k = 0; k < PGM_KX; ++k) {
+            rk8[k] = (rowvalid && !geny) ? niy.d[k] : 0u;
+            cyv[k] = (rowvalid && !geny) ? niy.c[k] : INFINITY;
+            lk4[k] = (uint32_t)(lane * 4) - (rk8[k] >> 6);
+        }
+        const int nyw = pgm_wave_max8(geny ? 0u : (fy & 7u));
+        const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
+        const float gopen_x = (rowvalid && y == 0) ? sg : gi;
+        const bool has_next = (b + 1 < nb);
+        const bool has_prev = (b > 0);
+        float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
+        const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
+        const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;
+        const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
+        const float4 *ni2q = (const float4 *)J.ni2;
+        int xr = (R - lane) % R;
+
+        // ---- the skip-edge terms of one step, split in three parts (shared by all roles) -----------------------
+        const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
+        constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
+        const uint32_t lane4 = (uint32_t)lane * 4u;
+        auto load_cols = [&](const float4 *rc, const float4 aux, uint32_t (&cj8)[PGM_KX], float (&cxv)[PGM_KX]) {
+            const float4 q1 = rc[1], q2 = rc[2], q3 = rc[3];
+            cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
+            cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
+            cj8[6] = __float_as_uint(q2.x);
+            cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
+        };
+        // part 1: column extras j -> X term and the M term with the chain row (source lane l-1)
+        auto part_cols = [&](uint32_t t8, int nxw, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn, float &Xn) {
+#pragma unroll
+            for (int j = 0; j < PGM_KX; ++j) {
+                if (j < nxw) {
+                    const uint32_t tj8 = t8 - cj8[j];
+                    const float Wj = *(const float *)(hWb + ((tj8 & MW) | lane4));
+                    const float Xj = *(const float *)(hXb + ((tj8 & MH) | lane4));
+                    const float W1 = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
+                    Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj, ge), __fadd_rn(Wj, gopen_x)), cxv[j]));
+                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cxv[j]));
+                }
+            }
+        };
+        // part 2: row extras k -> Y term, M term with the chain column; plus the pairs of row extra 0
+        auto part_rows = [&](uint32_t t8, int nxw, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float ccx,
+                             float gopen_y, float &Mn, float &Yn) {
+#pragma unroll
+            for (int k = 0; k < PGM_KX; ++k) {
+                if (k < nyw) {
+                    const uint32_t tk8 = t8 - rk8[k];
+                    const float Wk = *(const float *)(hWb + ((tk8 & MW) | lk4[k]));
+                    const float Yk = *(const float *)(hYb + ((tk8 & MH) | lk4[k]));
+                    const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | lk4[k]));
+                    Yn = fmaxf(Yn, __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y)), cyv[k]));
+                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), cyv[k]), ccx));
+                    if (k == 0) {
+#pragma unroll
+                        for (int j = 0; j < PGM_KX; ++j) {
+                            if (j < nxw) {
+                                const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
+                                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // part 3: the pairs (row extra k >= 1) x (column extra j)
+        auto part_pairs = [&](uint32_t t8, int nxw, uint32_t fx, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn) {
+#pragma unroll
+            for (int k = 1; k < PGM_KX; ++k) {
+                if (k < nyw) {
+                    const int nxk = pgm_wave_max8(rk8[k] != 0u ? (fx & 7u) : 0u);
+                    const uint32_t tk8 = t8 - rk8[k];
+#pragma unroll
+                    for (int j = 0; j < PGM_KX; ++j) {
+                        if (j < nxk) {
+                            const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
+                            Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
+                        }
+                    }
+                }
+            }
+        };
+
+        if (role == 0) {
+            for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
+            for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
+            if (lane == 0) {
+                main_done = -1; lds_abort = 0;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) help_done[h] = -1;
+            }
+        }
+
+        if (role == 0) {
+            // =========================================== main wavefront ===========================================
+            float W_left = PGM_NEG_INF, X_left = PGM_NEG_INF, W_diag = PGM_NEG_INF;
+            float W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
+            float4 pfq[PFQ];
+            constexpr int PFR = BL * HR / 64;
+            float2 pfr[PFR];
+            float4 pfs[BL / 4];
+            auto load_ring_block = [&](uint32_t c0) {
+#pragma unroll
+                for (int u = 0; u < PFQ; ++u) {
+                    const int idx = lane + 64 * u;
+                    const uint32_t col = c0 + (uint32_t)(idx / NQ);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < BL * NQ && col <= ncol) v = ni2q[(size_t)NQ * col + (idx % NQ)];
+                    pfq[u] = v;
+                }
+            };
+            auto store_ring_block = [&](uint32_t c0) {
+#pragma unroll
+                for (int u = 0; u < PFQ; ++u) {
+                    const int idx = lane + 64 * u;
+                    const uint32_t col = c0 + (uint32_t)(idx / NQ);
+                    if (idx < BL * NQ) ring[(col % R) * NQ + (idx % NQ)] = pfq[u];
+                }
+            };
+            auto load_rep_block = [&](uint32_t s0) {
+#pragma unroll
+                for (int u = 0; u < PFR; ++u) {
+                    const int e = lane * PFR + u;
+                    const uint32_t st = s0 + (uint32_t)(e / HR) + (uint32_t)RC;
+                    const int l = e % HR;
+                    float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
+                    if (has_prev && st < tsteps) v = pgm_load_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
+                    pfr[u] = v;
+                }
+            };
+            auto store_rep_block = [&]() {
+#pragma unroll
+                for (int u = 0; u < PFR; ++u) rep[lane * PFR + u] = pfr[u];
+            };
+            auto load_s_block = [&](uint32_t s0) {
+                const uint32_t tb = s0 / BL;
+#pragma unroll
+                for (int q = 0; q < BL / 4; ++q) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (comp && tb < nblk) v = S_band[((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q];
+                    pfs[q] = v;
+                }
+            };
+            auto store_s_block = [&](uint32_t s0) {   // scores of the block starting at step s0 -> buffer (s0 / BL) & 1
+                float *dst = sblk + ((s0 / BL) & 1u) * (BL * 64);
+#pragma unroll
+                for (int q = 0; q < BL / 4; ++q) {
+                    dst[(4 * q) * 64 + lane] = pfs[q].x;
+                    dst[(4 * q + 1) * 64 + lane] = pfs[q].y;
+                    dst[(4 * q + 2) * 64 + lane] = pfs[q].z;
+                    dst[(4 * q + 3) * 64 + lane] = pfs[q].w;
+                }
+            };
+            int seen = has_prev ? 0 : 0x7fffffff, pend = 0;
+            auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
+                if (seen != 0x7fffffff && !aborted) {
+                    const int need = (int)min(steps_needed, tsteps);
+                    uint32_t spins = 0;
+                    while (seen < need) {
+                        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (seen >= need) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            aborted = true;
+                            break;
+                        }
+                    }
+                }
+            };
+            // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
+            // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
+            auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
+            // prologue: column summaries and scores of blocks 0 and 1 straight in, block 2 in flight; replay tile of
+            // block 0 in, block 1 in flight
+            load_ring_block(0); store_ring_block(0);
+            load_s_block(0); store_s_block(0);
+            load_ring_block(BL); store_ring_block(BL);
+            load_s_block(BL); store_s_block(BL);
+            wait_prev(BL + RC + BL);
+            load_rep_block(0); store_rep_block();
+            load_ring_block(2 * BL);
+            load_s_block(2 * BL);
+            load_rep_block(BL);
+            poll_issue();
+            if (need_help) __syncthreads();   // history / counters initialised, first two blocks staged
+
+            for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
+                if (t0 > 0) {
+                    store_ring_block(t0 + BL);     // one block before use (helpers run ahead of this wavefront)
+                    store_s_block(t0 + BL);
+                    store_rep_block();
+                    load_ring_block(t0 + 2 * BL);
+                    load_s_block(t0 + 2 * BL);
+                    poll_collect();
+                    wait_prev(t0 + BL + BL + RC);
+                    load_rep_block(t0 + BL);
+                    poll_issue();
+                }
+                const float *scur = sblk + ((t0 / BL) & 1u) * (BL * 64);
+#pragma unroll 1
+                for (int i = 0; i < BL; ++i) {
+                    const uint32_t t = t0 + i;
+                    const int xs = (int)t - lane;
+                    const bool incol = xs >= 0 && xs < (int)ncol;
+                    const bool active = rowvalid && incol;
+                    const uint32_t x = (uint32_t)xs;
+                    const float4 *rc = ring + xr * NQ;
+                    xr = (xr + 1 == R) ? 0 : xr + 1;
+                    const float4 aux = rc[0];
+                    const float S = scur[i * 64 + lane];
+                    const float ccx = aux.x;
+                    const uint32_t fx = __float_as_uint(aux.y);
+                    const bool genx = active && (fx & 8u) != 0;
+                    const bool xkill = active && (fx & 16u) != 0;
+                    const float gopen_y = (xs == 0) ? sg : gi;
+                    const float W_up = pgm_dpp_wave_shr1(W_o, PGM_NEG_INF);
+                    const float Y_up = pgm_dpp_wave_shr1(Y_o, PGM_NEG_INF);
+                    float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_diag, S), ccy), ccx);
+                    float Xv = __fsub_rn(fmaxf(__fadd_rn(X_left, ge), __fadd_rn(W_left, gopen_x)), ccx);
+                    float Yv = __fsub_rn(fmaxf(__fadd_rn(Y_up, ge), __fadd_rn(W_up, gopen_y)), ccy);
+                    const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
+                    if (need_help) {
+                        // partial maxima of the helpers for this step
+                        uint32_t spins = 0;
+                        for (;;) {
+                            const int d0 = __hip_atomic_load(&help_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int d1 = __hip_atomic_load(&help_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int d2 = __hip_atomic_load(&help_done[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (min(d0, min(d1, d2)) >= (int)t) break;
+                            if (++spins > PGM_SPIN_LIMIT) { aborted = true; break; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                        const float *rs = res + (t & 3u) * (5 * 64) + lane;
+                        const float m1 = rs[0], x1 = rs[64], m2 = rs[128], y2 = rs[192], m3 = rs[256];
+                        if (!overflow) {
+                            Mv = fmaxf(Mv, fmaxf(m1, fmaxf(m2, m3)));
+                            Xv = fmaxf(Xv, x1);
+                            Yv = fmaxf(Yv, y2);
+                        }
+                    }
+                    const bool gen = active && (geny || genx || overflow);
+                    if (__builtin_amdgcn_ballot_w64(gen) != 0) {
+                        if (gen) {
+                            const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
+                            for (uint32_t e = xby; e < xey; ++e) {
+                                const uint32_t yp = J.xc1[e];
+                                const float cy = J.xv1[e];
+                                const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
+                                Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
+                                if (x > 0) {
+                                    const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x - 1));
+                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
+                                }
+                                for (uint32_t f = xbx; f < xex; ++f) {
+                                    const uint32_t xp = J.xc2[f];
+                                    const float cx = J.xv2[f];
+                                    const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
+                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
+                                }
+                            }
+                            for (uint32_t f = xbx; f < xex; ++f) {
+                                const uint32_t xp = J.xc2[f];
+                                const float cx = J.xv2[f];
+                                const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
+                                const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
+                                Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
+                                if (y > 0) {
+                                    const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, y - 1, xp));
+                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), ccy), cx));
+                                }
+                            }
+                        }
+                    }
+                    if (ykill) Xv = PGM_NEG_INF;
+                    if (xkill) Yv = PGM_NEG_INF;
+                    float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
+                    if (rowvalid && y == 0 && xs == 0) Wv = s_init;
+                    if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
+                    if (!comp) {
+                        const float2 rv = rep[i * HR + (lane & (HR - 1))];
+                        Wv = incol ? rv.x : PGM_NEG_INF;
+                        Yv = incol ? rv.y : PGM_NEG_INF;
+                    }
+                    if (active) {
+                        pgm_store_cell(cells_rsrc, t, lane, Mv, Xv, Wv, Yv);
+                        W_left = Wv;
+                        X_left = Xv;
+                    }
+                    {
+                        const int ho = (int)((t & (H - 1)) << 6) + lane;
+                        hW[ho] = Wv;
+                        hY[ho] = Yv;
+                        hX[ho] = Xv;
+                    }
+                    W_diag = W_up;
+                    W_o = Wv;
+                    Y_o = Yv;
+                    if (need_help) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        if (lane == 0) __hip_atomic_store(&main_done, (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (has_next) {
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
+                    if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (need_help && aborted && lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // =========================================== helper wavefronts ==========================================
+            __syncthreads();   // matches the main wavefront's barrier after initialisation
+            const int h = role - 1;
+            const uint32_t tend = (tsteps + BL - 1) / BL * BL;   // the main wavefront always finishes its last block
+            for (uint32_t t = 0; t < tend; ++t) {
+                // history up to step t-2 must be in place
+                uint32_t spins = 0;
+                bool stop = false;
+                while (__hip_atomic_load(&main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)t - 2) {
+                    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > PGM_SPIN_LIMIT) { stop = true; break; }
+                }
+                if (stop) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                const int xs = (int)t - lane;
+                const float4 *rc = ring + xr * NQ;
+                xr = (xr + 1 == R) ? 0 : xr + 1;
+                const float4 aux = rc[0];
+                const float S = sblk[((t / BL) & 1u) * (BL * 64) + (t % BL) * 64 + lane];
+                const float ccx = aux.x;
+                const uint32_t fx = __float_as_uint(aux.y);
+                const float gopen_y = (xs == 0) ? sg : gi;
+                const int nxw = pgm_wave_max8(fx & 7u);
+                const uint32_t t8 = t << 8;
+                float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF, Yn = PGM_NEG_INF;
+                uint32_t cj8[PGM_KX];
+                float cxv[PGM_KX];
+                if (nxw > 0) load_cols(rc, aux, cj8, cxv);
+                float *rs = res + (t & 3u) * (5 * 64) + lane;
+                if (h == 0) {
+                    if (!(DUMMY & 1) && nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
+                    rs[0] = Mn; rs[64] = Xn;
+                } else if (h == 1) {
+                    if (!(DUMMY & 2) && nyw > 0) part_rows(t8, nxw, cj8, cxv, S, ccx, gopen_y, Mn, Yn);
+                    rs[128] = Mn; rs[192] = Yn;
+                } else {
+                    if (!(DUMMY & 4) && nyw > 1 && nxw > 0) part_pairs(t8, nxw, fx, cj8, cxv, S, Mn);
+                    rs[256] = Mn;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (need_help) __syncthreads();   // band finished: nobody reads the history any more
     }
 }
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -73,6 +74,7 @@ struct pgm_align_batch {
     size_t sync_ints = 0, s_bytes = 0;
     PgmWorker *d_workers = nullptr;
     uint32_t nworkers = 0, maxnblk = 0;
+    bool any_extras = false, use_helpers = false;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
     size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0, out_bytes = 0;
@@ -226,9 +228,24 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // so the walks of all small jobs overlap the fill of the large ones.
     if ((e = hipEventRecord(ctx->ev_ready, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    const char *dbg = getenv("PGM_FILL_DBG");
+    const int dbgv = dbg ? atoi(dbg) : 0;
+    if (0) {}
+    else if (b->use_helpers && dbgv == 1) hipLaunchKernelGGL((pgm_fill_kernel4<1>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 2) hipLaunchKernelGGL((pgm_fill_kernel4<2>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 3) hipLaunchKernelGGL((pgm_fill_kernel4<3>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 4) hipLaunchKernelGGL((pgm_fill_kernel4<4>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 5) hipLaunchKernelGGL((pgm_fill_kernel4<5>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 6) hipLaunchKernelGGL((pgm_fill_kernel4<6>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 7) hipLaunchKernelGGL((pgm_fill_kernel4<7>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers) hipLaunchKernelGGL((pgm_fill_kernel4<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (dbgv == 1) hipLaunchKernelGGL((pgm_fill_kernel<1>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (dbgv == 2) hipLaunchKernelGGL((pgm_fill_kernel<2>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (dbgv == 3) hipLaunchKernelGGL((pgm_fill_kernel<3>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (dbgv == 4) hipLaunchKernelGGL((pgm_fill_kernel<4>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, ctx->stream2, b->d_jobs, b->d_sync);
+    if (dbgv == 0) hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, ctx->stream2, b->d_jobs, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if ((e = hipEventRecord(ctx->ev_tb, ctx->stream2)) != hipSuccess) return e;
@@ -282,6 +299,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
         }
         extras_frac[i] = 0.5 * ((double)o.s1.nodes_with_extras / a->n + (double)o.s2.nodes_with_extras / c->n);
+        J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
+        b->any_extras |= J.has_extras != 0;
         o.M = A.put(model[i]->M, sizeof(double) * a->dim * a->dim);
         o.pi = A.put(model[i]->pi, sizeof(double) * a->dim);
         o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
@@ -345,7 +364,11 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // wave-steps of each job (largest job first so that its workers are dispatched first)
     std::vector<PgmWorker> workers;
     if (njobs) {
-        const uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 4u;
+        // helper-wavefront kernel (4 wavefronts, 39 KB LDS per worker): 3 workers per CU; single-wavefront kernel: 4 per CU
+        const char *env_h = getenv("PGM_FILL_HELPERS");
+        b->use_helpers = (b->any_extras && !(env_h && env_h[0] == '0')) || (env_h && env_h[0] == '2');   // 0 / 2: experiments (never / always)
+        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * (b->use_helpers ? 3u : 4u);
+        if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         // Makespan-greedy: a job swept by W workers takes about (ceil(nb/W) * tsteps + (min(W,nb)-1) * lag) steps of
         // cost tau, tau growing with the share of nodes that carry skip-edge predecessors (measured: 0.4 us/step
         // for chains, 2.2 us/step at 60 %).  Every worker goes to the job that currently finishes last.

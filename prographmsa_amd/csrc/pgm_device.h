@@ -48,6 +48,7 @@ struct PgmJob {
     uint32_t ncol;         // stored columns = n2-1
     uint32_t tsteps;       // steps per band = ncol + 63
     uint32_t maxn;         // max(n1,n2)
+    uint32_t has_extras;   // some node of either graph has a predecessor other than its chain neighbour
     pgm_scores sc;
 
     // inputs as uploaded
