@@ -597,8 +597,14 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
     __shared__ float hX[H * 64];
     __shared__ float2 rep[BL * HR];
     __shared__ float sblk[2 * BL * 64];
-    __shared__ float res[4 * 5 * 64];      // [step & 3][field][lane]; fields: H1.M, H1.X, H2.M, H2.Y, H3.M
-    __shared__ int main_done, help_done[NH], lds_abort;
+    __shared__ float res1[4 * 2 * 64];     // [step & 3][M, X][lane]: partial maxima of helper 1 (plain stores)
+    __shared__ float resA[4 * 2 * 64];     // [step & 3][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
+    __shared__ uint32_t el_a[PGM_ENT];     // row-extra entries of the band: distance << 8 | owner lane
+    __shared__ float el_c[PGM_ENT];        //                                 edge cost
+    __shared__ uint32_t ovf[64];           // rows whose entries did not fit (they take the generic path)
+    __shared__ int el_cnt;
+    __shared__ __attribute__((aligned(16))) int help_done[4];   // last step each helper has finished (read with one 16-byte LDS load)
+    __shared__ int main_done, lds_abort;
 
     const PgmWorker wk = workers[blockIdx.x];
     const PgmJob &J = jobs[wk.job];
@@ -620,6 +626,7 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
         const uint32_t fy = rowvalid ? niy.flags : 0u;
         const uint32_t dymax = (fy >> 8) & 255u;
         const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
+        bool geny_m = geny;   // main wavefront: plus the rows whose entries overflowed the list
         const bool ykill = (fy & 16u) != 0;
         uint32_t rk8[PGM_KX], lk4[PGM_KX];
         float cyv[PGM_KX];
@@ -629,7 +636,6 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             cyv[k] = (rowvalid && !geny) ? niy.c[k] : INFINITY;
             lk4[k] = (uint32_t)(lane * 4) - (rk8[k] >> 6);
         }
-        const int nyw = pgm_wave_max8(geny ? 0u : (fy & 7u));
         const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
         const float gopen_x = (rowvalid && y == 0) ? sg : gi;
         const bool has_next = (b + 1 < nb);
@@ -641,7 +647,7 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
         const float4 *ni2q = (const float4 *)J.ni2;
         int xr = (R - lane) % R;
 
-        // ---- the skip-edge terms of one step, split in three parts (shared by all roles) -----------------------
+        // ---- history addressing shared by the helper roles ----------------------------------------------------------
         const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
         constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
         const uint32_t lane4 = (uint32_t)lane * 4u;
@@ -652,69 +658,54 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             cj8[6] = __float_as_uint(q2.x);
             cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
         };
+        // The history is read in batches: inside a chunk nothing is conditional (an absent extra has
+        // distance 0 and cost +inf, so its term is -inf whatever the slot holds), which lets all LDS reads of the chunk be
+        // issued back to back instead of one LDS round trip per term.
         // part 1: column extras j -> X term and the M term with the chain row (source lane l-1)
+        auto cols_chunk = [&](auto j0c, auto j1c, uint32_t t8, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn, float &Xn) {
+            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+            float Wj[J1 - J0], Xj[J1 - J0], W1[J1 - J0];
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                const uint32_t tj8 = t8 - cj8[j];
+                Wj[j - J0] = *(const float *)(hWb + ((tj8 & MW) | lane4));
+                Xj[j - J0] = *(const float *)(hXb + ((tj8 & MH) | lane4));
+                W1[j - J0] = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
+            }
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj[j - J0], ge), __fadd_rn(Wj[j - J0], gopen_x)), cxv[j]));
+                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1[j - J0], S), ccy), cxv[j]));
+            }
+        };
         auto part_cols = [&](uint32_t t8, int nxw, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn, float &Xn) {
-#pragma unroll
-            for (int j = 0; j < PGM_KX; ++j) {
-                if (j < nxw) {
-                    const uint32_t tj8 = t8 - cj8[j];
-                    const float Wj = *(const float *)(hWb + ((tj8 & MW) | lane4));
-                    const float Xj = *(const float *)(hXb + ((tj8 & MH) | lane4));
-                    const float W1 = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
-                    Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj, ge), __fadd_rn(Wj, gopen_x)), cxv[j]));
-                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cxv[j]));
-                }
-            }
-        };
-        // part 2: row extras k -> Y term, M term with the chain column; plus the pairs of row extra 0
-        auto part_rows = [&](uint32_t t8, int nxw, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float ccx,
-                             float gopen_y, float &Mn, float &Yn) {
-#pragma unroll
-            for (int k = 0; k < PGM_KX; ++k) {
-                if (k < nyw) {
-                    const uint32_t tk8 = t8 - rk8[k];
-                    const float Wk = *(const float *)(hWb + ((tk8 & MW) | lk4[k]));
-                    const float Yk = *(const float *)(hYb + ((tk8 & MH) | lk4[k]));
-                    const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | lk4[k]));
-                    Yn = fmaxf(Yn, __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y)), cyv[k]));
-                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), cyv[k]), ccx));
-                    if (k == 0) {
-#pragma unroll
-                        for (int j = 0; j < PGM_KX; ++j) {
-                            if (j < nxw) {
-                                const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
-                                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
-                            }
-                        }
-                    }
-                }
-            }
-        };
-        // part 3: the pairs (row extra k >= 1) x (column extra j)
-        auto part_pairs = [&](uint32_t t8, int nxw, uint32_t fx, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn) {
-#pragma unroll
-            for (int k = 1; k < PGM_KX; ++k) {
-                if (k < nyw) {
-                    const int nxk = pgm_wave_max8(rk8[k] != 0u ? (fx & 7u) : 0u);
-                    const uint32_t tk8 = t8 - rk8[k];
-#pragma unroll
-                    for (int j = 0; j < PGM_KX; ++j) {
-                        if (j < nxk) {
-                            const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
-                            Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
-                        }
-                    }
-                }
-            }
+            cols_chunk(std::integral_constant<int, 0>(), std::integral_constant<int, 4>(), t8, cj8, cxv, S, Mn, Xn);
+            if (nxw > 4) cols_chunk(std::integral_constant<int, 4>(), std::integral_constant<int, PGM_KX>(), t8, cj8, cxv, S, Mn, Xn);
         };
 
         if (role == 0) {
             for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
             for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
+            for (int i = lane; i < 4 * 2 * 64; i += 64) resA[i] = PGM_NEG_INF;
             if (lane == 0) {
                 main_done = -1; lds_abort = 0;
+                help_done[0] = -1; help_done[1] = -1; help_done[2] = -1; help_done[3] = 0x7fffffff;
+            }
+        } else if (role == 2) {
+            // Row-extra entry list of this band (order irrelevant): each row appends its extras at a position taken from
+            // an LDS counter.  LDS operations of one wavefront execute in order, so the reset below precedes the adds.
+            if (lane == 0) el_cnt = 0;
+            const uint32_t cnt = (rowvalid && !geny) ? (fy & 7u) : 0u;
+            uint32_t base = 0;
+            if (cnt) base = (uint32_t)__hip_atomic_fetch_add(&el_cnt, (int)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool ov = cnt != 0 && base + cnt > (uint32_t)PGM_ENT;
+            ovf[lane] = ov ? 1u : 0u;
 #pragma unroll
-                for (int h = 0; h < NH; ++h) help_done[h] = -1;
+            for (int k = 0; k < PGM_KX; ++k) {
+                if ((uint32_t)k < cnt && base + k < (uint32_t)PGM_ENT) {
+                    el_a[base + k] = ov ? (uint32_t)lane : (rk8[k] | (uint32_t)lane);
+                    el_c[base + k] = ov ? INFINITY : cyv[k];
+                }
             }
         }
 
@@ -811,8 +802,15 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             load_s_block(2 * BL);
             load_rep_block(BL);
             poll_issue();
-            if (need_help) __syncthreads();   // history / counters initialised, first two blocks staged
+            if (need_help) {
+                __syncthreads();   // history / counters initialised, first two blocks staged, entry list built
+                geny_m = geny || ovf[lane] != 0;
+            }
 
+            unsigned long long mcyc_wait = 0;
+            float2 aux_n = *(const float2 *)(ring + xr * NQ), rep_n = make_float2(PGM_NEG_INF, PGM_NEG_INF);   // operands of step 0
+            float S_n = sblk[lane];
+            const unsigned long long mc_start = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
             for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
                 if (t0 > 0) {
                     store_ring_block(t0 + BL);     // one block before use (helpers run ahead of this wavefront)
@@ -825,7 +823,9 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     load_rep_block(t0 + BL);
                     poll_issue();
                 }
-                const float *scur = sblk + ((t0 / BL) & 1u) * (BL * 64);
+                // LDS operands of a step are read one step ahead (aux2 / S of the next column are already staged; the replay
+                // tile only inside its block), so no LDS round trip sits between two steps of the chain.
+                rep_n = rep[lane & (HR - 1)];
 #pragma unroll 1
                 for (int i = 0; i < BL; ++i) {
                     const uint32_t t = t0 + i;
@@ -833,10 +833,13 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     const bool incol = xs >= 0 && xs < (int)ncol;
                     const bool active = rowvalid && incol;
                     const uint32_t x = (uint32_t)xs;
-                    const float4 *rc = ring + xr * NQ;
+                    const float2 aux = aux_n;
+                    const float S = S_n;
+                    const float2 rv = rep_n;
                     xr = (xr + 1 == R) ? 0 : xr + 1;
-                    const float4 aux = rc[0];
-                    const float S = scur[i * 64 + lane];
+                    aux_n = *(const float2 *)(ring + xr * NQ);
+                    S_n = sblk[(((t + 1) / BL) & 1u) * (BL * 64) + ((t + 1) % BL) * 64 + lane];
+                    rep_n = rep[min(i + 1, BL - 1) * HR + (lane & (HR - 1))];
                     const float ccx = aux.x;
                     const uint32_t fx = __float_as_uint(aux.y);
                     const bool genx = active && (fx & 8u) != 0;
@@ -850,24 +853,31 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
                     if (need_help) {
                         // partial maxima of the helpers for this step
+                        const unsigned long long mc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                        // One LDS round trip in the common case: the counter and the partials are read together; LDS
+                        // executes a wavefront's operations in order, so partials read after a complete counter are final.
+                        const float *r1 = res1 + (t & 3u) * (2 * 64) + lane;
+                        float *ra = resA + (t & 3u) * (2 * 64) + lane;
+                        float m1, x1, m2, y2;
                         uint32_t spins = 0;
                         for (;;) {
-                            const int d0 = __hip_atomic_load(&help_done[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const int d1 = __hip_atomic_load(&help_done[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const int d2 = __hip_atomic_load(&help_done[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (min(d0, min(d1, d2)) >= (int)t) break;
+                            asm volatile("" ::: "memory");
+                            const int4 hd = *(const int4 *)help_done;
+                            asm volatile("" ::: "memory");
+                            m1 = r1[0]; x1 = r1[64]; m2 = ra[0]; y2 = ra[64];
+                            asm volatile("" ::: "memory");
+                            if (min(min(hd.x, hd.y), hd.z) >= (int)t) break;
                             if (++spins > PGM_SPIN_LIMIT) { aborted = true; break; }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                        const float *rs = res + (t & 3u) * (5 * 64) + lane;
-                        const float m1 = rs[0], x1 = rs[64], m2 = rs[128], y2 = rs[192], m3 = rs[256];
+                        if (DUMMY & 8) mcyc_wait += __builtin_readcyclecounter() - mc0;
+                        ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 4
                         if (!overflow) {
-                            Mv = fmaxf(Mv, fmaxf(m1, fmaxf(m2, m3)));
+                            Mv = fmaxf(Mv, fmaxf(m1, m2));
                             Xv = fmaxf(Xv, x1);
                             Yv = fmaxf(Yv, y2);
                         }
                     }
-                    const bool gen = active && (geny || genx || overflow);
+                    const bool gen = active && (geny_m || genx || overflow);
                     if (__builtin_amdgcn_ballot_w64(gen) != 0) {
                         if (gen) {
                             const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
@@ -906,7 +916,6 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     if (rowvalid && y == 0 && xs == 0) Wv = s_init;
                     if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
                     if (!comp) {
-                        const float2 rv = rep[i * HR + (lane & (HR - 1))];
                         Wv = incol ? rv.x : PGM_NEG_INF;
                         Yv = incol ? rv.y : PGM_NEG_INF;
                     }
@@ -925,7 +934,7 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     W_o = Wv;
                     Y_o = Yv;
                     if (need_help) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        asm volatile("" ::: "memory");   // LDS executes in order: the history writes above precede this flag
                         if (lane == 0) __hip_atomic_store(&main_done, (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
@@ -934,6 +943,7 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            if ((DUMMY & 8) && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
             if (need_help && aborted && lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -942,43 +952,130 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             __syncthreads();   // matches the main wavefront's barrier after initialisation
             const int h = role - 1;
             const uint32_t tend = (tsteps + BL - 1) / BL * BL;   // the main wavefront always finishes its last block
-            for (uint32_t t = 0; t < tend; ++t) {
-                // history up to step t-2 must be in place
+            unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+            // history up to step t-2 must be in place before the history reads of step t
+            auto wait_main = [&](uint32_t t) -> bool {
                 uint32_t spins = 0;
-                bool stop = false;
                 while (__hip_atomic_load(&main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)t - 2) {
-                    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > PGM_SPIN_LIMIT) { stop = true; break; }
+                    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > PGM_SPIN_LIMIT) return false;
                 }
-                if (stop) break;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-                const int xs = (int)t - lane;
-                const float4 *rc = ring + xr * NQ;
-                xr = (xr + 1 == R) ? 0 : xr + 1;
-                const float4 aux = rc[0];
-                const float S = sblk[((t / BL) & 1u) * (BL * 64) + (t % BL) * 64 + lane];
-                const float ccx = aux.x;
-                const uint32_t fx = __float_as_uint(aux.y);
-                const float gopen_y = (xs == 0) ? sg : gi;
-                const int nxw = pgm_wave_max8(fx & 7u);
-                const uint32_t t8 = t << 8;
-                float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF, Yn = PGM_NEG_INF;
-                uint32_t cj8[PGM_KX];
-                float cxv[PGM_KX];
-                if (nxw > 0) load_cols(rc, aux, cj8, cxv);
-                float *rs = res + (t & 3u) * (5 * 64) + lane;
-                if (h == 0) {
+                asm volatile("" ::: "memory");
+                return true;
+            };
+            if (h == 0) {
+                // ---- helper 1: column extras, one row per lane like the main wavefront -----------------------------
+                for (uint32_t t = 0; t < tend; ++t) {
+                    const float4 *rc = ring + xr * NQ;
+                    xr = (xr + 1 == R) ? 0 : xr + 1;
+                    const float4 aux = rc[0];
+                    const float S = sblk[((t / BL) & 1u) * (BL * 64) + (t % BL) * 64 + lane];
+                    const uint32_t fx = __float_as_uint(aux.y);
+                    const int nxw = pgm_wave_max8(fx & 7u);
+                    const uint32_t t8 = t << 8;
+                    float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF;
+                    uint32_t cj8[PGM_KX];
+                    float cxv[PGM_KX];
+                    if (nxw > 0) load_cols(rc, aux, cj8, cxv);
+                    const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    if (!wait_main(t)) break;
+                    const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     if (!(DUMMY & 1) && nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
+                    float *rs = res1 + (t & 3u) * (2 * 64) + lane;
                     rs[0] = Mn; rs[64] = Xn;
-                } else if (h == 1) {
-                    if (!(DUMMY & 2) && nyw > 0) part_rows(t8, nxw, cj8, cxv, S, ccx, gopen_y, Mn, Yn);
-                    rs[128] = Mn; rs[192] = Yn;
-                } else {
-                    if (!(DUMMY & 4) && nyw > 1 && nxw > 0) part_pairs(t8, nxw, fx, cj8, cxv, S, Mn);
-                    rs[256] = Mn;
+                    asm volatile("" ::: "memory");   // in-order LDS: the partials above precede the flag
+                    if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc1 - hc0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                // ---- helpers 2 and 3: one ROW EXTRA (entry) per lane -----------------------------------------------
+                // A lane owns entry (row lane l, distance d, cost cy) for the whole band and evaluates, for the column
+                // x = t - l that row is at: helper 2 the row terms (Y, M with the chain column) and the pairs with
+                // column extras 0..2; helper 3 the pairs with column extras 3..6.  Rows have ~1 extra on average but
+                // up to 7, so a lane per entry does a few times less work than a lane per row with a loop to the
+                // wavefront's maximum count.  Results are merged per owner row with LDS float-max atomics (max is
+                // exact and order independent).  Up to PGM_ENT = 128 entries (two per lane).
+                const int nent = min(el_cnt, (int)PGM_ENT);
+                const bool two = nent > 64;
+                uint32_t e_l[2], e_rk8[2], e_lk4[2];
+                int e_xr[2];
+                float e_cy[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int w = lane + 64 * p;
+                    const bool valid = w < nent;
+                    const uint32_t a = valid ? el_a[w] : (uint32_t)lane;
+                    e_cy[p] = valid ? el_c[w] : INFINITY;
+                    e_l[p] = a & 255u;
+                    e_rk8[p] = a & ~255u;
+                    e_lk4[p] = e_l[p] * 4u - (e_rk8[p] >> 6);
+                    e_xr[p] = (R - (int)e_l[p]) % R;
+                }
+                for (uint32_t t = 0; t < tend; ++t) {
+                    const uint32_t t8 = t << 8;
+                    const float *sb = sblk + ((t / BL) & 1u) * (BL * 64) + (t % BL) * 64;
+                    float S[2], ccx[2], gopen_y[2];
+                    uint32_t dj[2][4];
+                    float cxs[2][4];
+                    bool any = false;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        if (p == 0 || two) {
+                            const float4 *rc = ring + e_xr[p] * NQ;
+                            e_xr[p] = (e_xr[p] + 1 == R) ? 0 : e_xr[p] + 1;
+                            S[p] = sb[e_l[p]];
+                            if (h == 1) {
+                                const float4 aux = rc[0], q2 = rc[2];
+                                const float q1x = rc[1].x;
+                                ccx[p] = aux.x;
+                                gopen_y[p] = (t == e_l[p]) ? sg : gi;
+                                dj[p][0] = __float_as_uint(aux.z); dj[p][1] = __float_as_uint(aux.w); dj[p][2] = __float_as_uint(q1x); dj[p][3] = 0u;
+                                cxs[p][0] = q2.y; cxs[p][1] = q2.z; cxs[p][2] = q2.w; cxs[p][3] = INFINITY;
+                                any = true;
+                            } else {
+                                const float4 q1 = rc[1], q3 = rc[3];
+                                const float q2x = rc[2].x;
+                                dj[p][0] = __float_as_uint(q1.y); dj[p][1] = __float_as_uint(q1.z); dj[p][2] = __float_as_uint(q1.w); dj[p][3] = __float_as_uint(q2x);
+                                cxs[p][0] = q3.x; cxs[p][1] = q3.y; cxs[p][2] = q3.z; cxs[p][3] = q3.w;
+                                any = any || (q3.x < INFINITY && e_cy[p] < INFINITY);   // column extra 3 exists (they are filled in order)
+                            }
+                        }
+                    }
+                    const bool work = __builtin_amdgcn_ballot_w64(any) != 0;
+                    const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    if (!wait_main(t)) break;
+                    const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    if (work && !(DUMMY & (h == 1 ? 2 : 4))) {
+                        float *ra = resA + (t & 3u) * (2 * 64);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            if (p == 0 || two) {
+                                const uint32_t tk8 = t8 - e_rk8[p];
+                                float W2[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (h == 2 || j < 3) W2[j] = *(const float *)(hWb + (((tk8 - dj[p][j]) & MW) | e_lk4[p]));
+                                float Mt = PGM_NEG_INF;
+                                if (h == 1) {
+                                    const float Wk = *(const float *)(hWb + ((tk8 & MW) | e_lk4[p]));
+                                    const float Yk = *(const float *)(hYb + ((tk8 & MH) | e_lk4[p]));
+                                    const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | e_lk4[p]));
+                                    const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y[p])), e_cy[p]);
+                                    Mt = __fsub_rn(__fsub_rn(__fadd_rn(W1, S[p]), e_cy[p]), ccx[p]);
+                                    __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(ra + 64 + e_l[p]), Yt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (h == 2 || j < 3) Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(W2[j], S[p]), e_cy[p]), cxs[p][j]));
+                                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(ra + e_l[p]), Mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                            }
+                        }
+                    }
+                    asm volatile("" ::: "memory");   // in-order LDS: the partials above precede the flag
+                    if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc1 - hc0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                }
             }
+            if ((DUMMY & 8) && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
         }
         if (need_help) __syncthreads();   // band finished: nobody reads the history any more
     }

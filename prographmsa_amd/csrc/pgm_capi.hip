@@ -238,6 +238,7 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     else if (b->use_helpers && dbgv == 5) hipLaunchKernelGGL((pgm_fill_kernel4<5>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     else if (b->use_helpers && dbgv == 6) hipLaunchKernelGGL((pgm_fill_kernel4<6>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     else if (b->use_helpers && dbgv == 7) hipLaunchKernelGGL((pgm_fill_kernel4<7>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    else if (b->use_helpers && dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel4<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     else if (b->use_helpers) hipLaunchKernelGGL((pgm_fill_kernel4<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     else if (dbgv == 1) hipLaunchKernelGGL((pgm_fill_kernel<1>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
     else if (dbgv == 2) hipLaunchKernelGGL((pgm_fill_kernel<2>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);

@@ -22,6 +22,7 @@
 //   d_k    (node - predecessor) << 8 of extra k, 0 if absent;   c_k its cost, +inf if absent (an absent
 //          extra therefore contributes -inf to every max without any masking)
 #define PGM_KX 7
+#define PGM_ENT 128       // row-extra entries per band handled by the entry wavefronts of the helper fill kernel
 struct PgmNodeInfo {
     float cc;
     uint32_t flags;

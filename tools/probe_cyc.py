@@ -1,4 +1,4 @@
-"""Cycle breakdown per block of the chain-only fill kernel (PGM_FILL_DBG=4 build variant) on the leaf level (GPU box)."""
+"""Cycle breakdown of the helper fill kernel (PGM_FILL_DBG=8 build variant) on the root job (GPU box)."""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,16 +13,13 @@ subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/
 jobs = J.load_jobs(dump)
 ctx = pg.Context(0)
 by = sorted(jobs, key=lambda j: j.cells)
-for n, w in ((1, 21), (16, 16), (32, 32), (128, 128), (128, 1024)):
-    os.environ["PGM_FILL_WORKERS"] = str(w)
-    b = J.Batch(ctx, by[:n])
-    os.environ["PGM_FILL_DBG"] = "0"
-    b.run(); b.fetch()
-    os.environ["PGM_FILL_DBG"] = "4"
-    p, e, f, t = b.time(1)
-    res = b.fetch()
-    os.environ["PGM_FILL_DBG"] = "0"
-    m = res[n // 2]["map1"][:84].reshape(21, 4)
-    print("jobs=%d workers<=%d fill=%.3f ms; job %d: cycles/block [start-section, of which wait_prev, 8 steps, publish] per band:" % (n, w, f, n // 2))
-    print(m.T, flush=True)
-    b.close()
+b = J.Batch(ctx, by[-1:])
+b.run(); b.fetch()
+os.environ["PGM_FILL_DBG"] = "8"
+p, e, f, t = b.time(1)
+res = b.fetch()
+os.environ["PGM_FILL_DBG"] = "0"
+nb = (by[-1].g1.n - 1 + 47) // 48
+m = res[0]["map1"][:8 * nb].reshape(nb, 8)
+print("root job fill=%.3f ms; cycles/step per band: [main wait, main total, h1 wait, h1 total, h2 wait, h2 total, h3 wait, h3 total]" % f)
+print(m[::3].T, flush=True)
