@@ -207,416 +207,90 @@ __device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y
     return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
 }
 
+#define PGM_SPIN_LIMIT (1u << 24)
+
 // ---------------------------------------------------------------------------------------------
 // Fill kernel (GraphAlign.h:212-260 incl. the border initialisation as row/column 0).
 //
-// Persistent grid of single-wavefront workers (64-thread workgroups, all co-resident).  A job is swept by
-// `nworkers` workers; worker `rank` takes the row bands rank, rank + nworkers, ...  A band is 48 rows: lanes
-// 16..63 own rows y = 48 b + l - 16 and at step t compute column x = t - l, so the three chain neighbours
-// (y-1,x-1), (y-1,x), (y,x-1) are in registers of lane l-1 (one DPP shift) or of the lane itself.  Lanes 0..15
-// do not compute: they REPLAY the last 16 rows of band b-1 (read back from the cell storage, one contiguous
-// 256 B run per step, staged through LDS a block ahead), so that every predecessor row within 16 rows of a
-// lane lives in a lower lane of the same wavefront.
+// Work unit = one BAND of one job: 48 consecutive rows of graph 1 against all columns of graph 2.  The bands of all
+// jobs of the batch sit in one list ordered by longest remaining path first (host side); a persistent grid of
+// workers (256-thread workgroups) takes them through an atomic ticket counter.  Band b of a job is always listed
+// after band b-1, so the worker it waits for already holds its band and is running: hand-offs cannot deadlock.
 //
-// Per-wavefront LDS:
-//   ring  : predecessor summary (PgmNodeInfo) of the last 80 columns, loaded one 16-column block ahead
-//   hW/hY/hX : W of all 64 lanes for the last 32 steps, Y and X for the last 16.  A skip-edge predecessor pair
-//           (y-dy, x-dx) was produced by lane l-dy exactly dy+dx steps ago, so merged-graph skip edges
-//           (distances of a few nodes) are served from this history without touching HBM.
-//   rep   : replay values {W,Y} of the current 16 steps;  sblk : emission scores of the current 16 steps
-// Nodes with a predecessor more than 15 nodes back or with more than 7 extra predecessors (far tandem-repeat
+// A worker is four wavefronts.  Wavefront 0 ("main") owns the band's dependency chain: lanes 16..63 own rows
+// y = 48 b + l - 16 and at step t compute column x = t - l, so the three chain neighbours (y-1,x-1), (y-1,x), (y,x-1)
+// are in registers of lane l-1 (one DPP shift) or of the lane itself.  Lanes 0..15 do not compute: they REPLAY the
+// last 16 rows of band b-1 (read back from the cell storage, one contiguous 256 B run per step, staged through LDS
+// a block ahead), so that every predecessor row within 16 rows of a lane lives in a lower lane of the same wavefront.
+// Wavefronts 1..3 ("helpers") evaluate the skip-edge terms of merged graphs; for a chain-only job they skip the band
+// and the main wavefront runs alone.  Every skip-edge term of step t needs history only up to step t-2 (an extra
+// predecessor is at least 2 nodes back), so the helpers work on step t+1 while the main wavefront does step t; one
+// hardware barrier per step ("tick") keeps the four in lock step.
+//   helper 1: column extras (X terms, M terms with the chain row), one row per lane, loop to the wavefront's max count
+//   helper 2: row extras: one (row, extra) ENTRY per lane: Y term, M term with the chain column, pairs with column extras 0..2
+//   helper 3: the same entries: pairs with column extras 3..6
+//
+// Per-worker LDS:
+//   ring  : predecessor summary (PgmNodeInfo) of the last 80 columns, stored two 8-column blocks ahead
+//   hW/hY/hX : W, Y, X of all 64 lanes for the last 32 steps.  A skip-edge predecessor pair (y-dy, x-dx) was produced
+//           by lane l-dy exactly dy+dx steps ago, so skip edges are served from this history without touching HBM.
+//   rep   : replay values {W,Y} of the current block;  sblk : emission scores of the current and the next block
+//   res1/resA : partial maxima of the helpers for the current and the next step
+// Nodes with a predecessor more than 31 nodes back or with more than 7 extra predecessors (far tandem-repeat
 // edges, pathological graphs) fall back to reading the cell storage (HBM/L2) for all their extras.
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
 // that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
-#define PGM_SPIN_LIMIT (1u << 24)
-
 template <int DUMMY>
-__global__ void __launch_bounds__(64) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmWorker *__restrict__ workers,
-                                                      int *__restrict__ abort_flag) {
-    constexpr int NQ = 4;            // PgmNodeInfo of a column = 4 float4
-    constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
-    constexpr int PFQ = (BL * NQ + 63) / 64;   // ring prefetch quads per lane (= 1)
-    __shared__ __attribute__((aligned(16))) float4 ring[R * NQ];
-    __shared__ float hW[HW * 64];
-    __shared__ float hY[H * 64];
-    __shared__ float hX[H * 64];
-    static_assert(PGM_HIST == PGM_HISTW, "all three history planes share one depth");
-    __shared__ float2 rep[BL * HR];
-    __shared__ float sblk[BL * 64];
-
-    const PgmWorker wk = workers[blockIdx.x];
-    const PgmJob &J = jobs[wk.job];
-    const int lane = threadIdx.x;
-    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
-    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
-    bool aborted = false;
-    for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (uint32_t b = wk.rank; b < nb && !aborted; b += wk.nworkers) {
-        const bool comp = lane >= HR;                       // compute lane (else replay lane)
-        const uint32_t y = RC * b + (uint32_t)(lane - HR);  // only meaningful for compute lanes
-        const bool rowvalid = comp && y + 1 < n1;           // rows 0..n1-2
-        const uint32_t yc = rowvalid ? y : 0u;
-        const PgmNodeInfo niy = J.ni1[yc];
-        const float ccy = niy.cc;
-        const uint32_t fy = rowvalid ? niy.flags : 0u;
-        const uint32_t dymax = (fy >> 8) & 255u;
-        // a row whose furthest extra predecessor lies above lane 0 of this wavefront cannot use the on-chip history
-        const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
-        const bool ykill = (fy & 16u) != 0;
-        // row extras as lane constants: rk8 = dy << 8 (history slot stride is 256 B), lk4 = byte offset of the source
-        // lane inside a slot, cyv = cost (+inf for an absent extra, which turns its terms into -inf)
-        uint32_t rk8[PGM_KX], lk4[PGM_KX];
-        float cyv[PGM_KX];
-#pragma unroll
-        for (int k = 0; k < PGM_KX; ++k) {
-            rk8[k] = (rowvalid && !geny) ? niy.d[k] : 0u;
-            cyv[k] = (rowvalid && !geny) ? niy.c[k] : INFINITY;
-            lk4[k] = (uint32_t)(lane * 4) - (rk8[k] >> 6);
-        }
-        const int nyw = pgm_wave_max8(geny ? 0u : (fy & 7u));   // band constant: most extras any row of this band has
-        const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
-        const float gopen_x = (rowvalid && y == 0) ? sg : gi;  // row 0 opens gaps with start_gap (GraphAlign.h:229)
-        const bool has_next = (b + 1 < nb);
-        const bool has_prev = (b > 0);
-        float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
-        const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
-        const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;  // only dereferenced if has_prev
-        const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
-        const float4 *ni2q = (const float4 *)J.ni2;
-
-        // history planes start at -inf (no NaN may ever be read from them)
-        for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
-        for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
-
-        float W_left = PGM_NEG_INF, X_left = PGM_NEG_INF, W_diag = PGM_NEG_INF;
-        float W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
-        int xr = (R - lane) % R;   // ring slot of this lane's column, advanced every step
-
-        // ---- data of the next block, in flight while the current block is computed -----------------
-        float4 pfq[PFQ];           // column summaries [c0, c0+16)
-        constexpr int PFR = BL * HR / 64;   // replay-tile elements per lane
-        static_assert(BL * HR % 64 == 0, "replay tile must divide evenly over the lanes");
-        float2 pfr[PFR];           // replay tile
-        float4 pfs[BL / 4];        // emission scores of this lane
-        auto load_ring_block = [&](uint32_t c0) {
-#pragma unroll
-            for (int u = 0; u < PFQ; ++u) {
-                const int idx = lane + 64 * u;
-                const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < BL * NQ && col <= ncol) v = ni2q[(size_t)NQ * col + (idx % NQ)];
-                pfq[u] = v;
-            }
-        };
-        auto store_ring_block = [&](uint32_t c0) {
-#pragma unroll
-            for (int u = 0; u < PFQ; ++u) {
-                const int idx = lane + 64 * u;
-                const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                if (idx < BL * NQ) ring[(col % R) * NQ + (idx % NQ)] = pfq[u];
-            }
-        };
-        // replay tile of the BL steps starting at s0: element e = i*16 + l -> {W,Y} of band b-1, step s0+i+48, lane 48+l
-        auto load_rep_block = [&](uint32_t s0) {
-#pragma unroll
-            for (int u = 0; u < PFR; ++u) {
-                const int e = lane * PFR + u;
-                const uint32_t st = s0 + (uint32_t)(e / HR) + (uint32_t)RC;
-                const int l = e % HR;
-                float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
-                if (has_prev && st < tsteps) v = pgm_load_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
-                pfr[u] = v;
-            }
-        };
-        auto store_rep_block = [&]() {
-#pragma unroll
-            for (int u = 0; u < PFR; ++u) rep[lane * PFR + u] = pfr[u];
-        };
-        auto load_s_block = [&](uint32_t s0) {
-            const uint32_t tb = s0 / BL;
-#pragma unroll
-            for (int q = 0; q < BL / 4; ++q) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (comp && tb < nblk) v = S_band[((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q];
-                pfs[q] = v;
-            }
-        };
-        auto store_s_block = [&]() {
-#pragma unroll
-            for (int q = 0; q < BL / 4; ++q) {
-                sblk[(4 * q) * 64 + lane] = pfs[q].x;
-                sblk[(4 * q + 1) * 64 + lane] = pfs[q].y;
-                sblk[(4 * q + 2) * 64 + lane] = pfs[q].z;
-                sblk[(4 * q + 3) * 64 + lane] = pfs[q].w;
-            }
-        };
-        int seen = has_prev ? 0 : 0x7fffffff, pend = 0;   // progress of band b-1: last value seen / value in flight
-        auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
-            if (seen != 0x7fffffff && !aborted) {
-                const int need = (int)min(steps_needed, tsteps);
-                uint32_t spins = 0;
-                while (seen < need) {
-                    seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (seen >= need) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        aborted = true;
-                        break;
-                    }
-                }
-            }
-        };
-        // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
-        // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
-        auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
-
-        // prologue: data of block 0 straight in, data of block 1 in flight
-        load_ring_block(0);
-        store_ring_block(0);
-        load_s_block(0);
-        store_s_block();
-        wait_prev(BL + RC + BL);
-        load_rep_block(0);
-        store_rep_block();
-        load_ring_block(BL);
-        load_s_block(BL);
-        load_rep_block(BL);
-        poll_issue();
-
-        unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0, cyc_w = 0;
-        for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
-            const unsigned long long c0 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
-            unsigned long long cw0 = 0, cw1 = 0;
-            if (t0 > 0) {
-                // data loaded during the previous block becomes current; start loading the next block
-                store_ring_block(t0);
-                store_rep_block();
-                store_s_block();
-                load_ring_block(t0 + BL);
-                load_s_block(t0 + BL);
-                poll_collect();
-                if (DUMMY == 4) cw0 = __builtin_readcyclecounter();
-                wait_prev(t0 + BL + BL + RC);   // replay tile of block t0+BL reads steps < t0+2BL+48 of band b-1
-                if (DUMMY == 4) cw1 = __builtin_readcyclecounter();
-                load_rep_block(t0 + BL);
-                poll_issue();
-            }
-            const unsigned long long c1 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
-#pragma unroll 1
-            for (int i = 0; i < BL; ++i) {
-                const uint32_t t = t0 + i;
-                const int xs = (int)t - lane;
-                const bool incol = xs >= 0 && xs < (int)ncol;
-                const bool active = rowvalid && incol;
-                const uint32_t x = (uint32_t)xs;
-                const float4 *rc = ring + xr * NQ;
-                xr = (xr + 1 == R) ? 0 : xr + 1;
-                const float4 aux = rc[0];   // {cc, flags, d0, d1} of column x
-                const float S = sblk[i * 64 + lane];
-                const float ccx = aux.x;
-                const uint32_t fx = __float_as_uint(aux.y);
-                const bool genx = active && (fx & 8u) != 0;
-                const bool xkill = active && (fx & 16u) != 0;
-                const float gopen_y = (xs == 0) ? sg : gi;  // column 0 opens gaps with start_gap (:218)
-
-                const float W_up = pgm_dpp_wave_shr1(W_o, PGM_NEG_INF);
-                const float Y_up = pgm_dpp_wave_shr1(Y_o, PGM_NEG_INF);
-
-                // chain x chain pair (GraphAlign.h:245-250)
-                float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_diag, S), ccy), ccx);
-                float Xv = __fsub_rn(fmaxf(__fadd_rn(X_left, ge), __fadd_rn(W_left, gopen_x)), ccx);
-                float Yv = __fsub_rn(fmaxf(__fadd_rn(Y_up, ge), __fadd_rn(W_up, gopen_y)), ccy);
-
-                // ---- skip-edge predecessors served from the LDS history --------------------------------------
-                // Everything below is branch-free per lane: an absent extra has cost +inf and distance 0, so its
-                // term evaluates to -inf.  nyw / nxw (wave-uniform maxima) only bound the unrolled loops.
-                const int nxw = pgm_wave_max8(fx & 7u);
-                // a pair (dy, dx) reaches dy+dx steps back; beyond the history depth the lane-step goes generic
-                const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
-                float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF, Yn = PGM_NEG_INF;
-                if (nyw > 0 || nxw > 0) {
-                    const uint32_t t8 = t << 8;
-                    const uint32_t lane4 = (uint32_t)lane * 4u;
-                    const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
-                    constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
-                    uint32_t cj8[PGM_KX];
-                    float cxv[PGM_KX];
-                    if (nxw > 0) {
-                        const float4 q1 = rc[1], q2 = rc[2], q3 = rc[3];
-                        cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
-                        cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
-                        cj8[6] = __float_as_uint(q2.x);
-                        cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
-                        // column extras: X term and the M term with the chain row (source lane l-1)
-#pragma unroll
-                        for (int j = 0; j < PGM_KX; ++j) {
-                            if (j < nxw) {
-                                const uint32_t tj8 = t8 - cj8[j];
-                                const float Wj = *(const float *)(hWb + ((tj8 & MW) | lane4));
-                                const float Xj = *(const float *)(hXb + ((tj8 & MH) | lane4));
-                                const float W1 = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
-                                Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj, ge), __fadd_rn(Wj, gopen_x)), cxv[j]));
-                                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cxv[j]));
-                            }
-                        }
-                    }
-                    // row extras: Y term, M term with the chain column, M terms with every column extra
-#pragma unroll
-                    for (int k = 0; k < PGM_KX; ++k) {
-                        if (k < nyw) {
-                            const uint32_t tk8 = t8 - rk8[k];
-                            const float Wk = *(const float *)(hWb + ((tk8 & MW) | lk4[k]));
-                            const float Yk = *(const float *)(hYb + ((tk8 & MH) | lk4[k]));
-                            const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | lk4[k]));
-                            Yn = fmaxf(Yn, __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y)), cyv[k]));
-                            Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1, S), cyv[k]), ccx));
-                            // pairs with the column extras: bounded by the most column extras among the lanes that
-                            // actually have a k-th row extra (few lanes for k >= 1)
-                            const int nxk = (k == 0 || nxw == 0) ? nxw : pgm_wave_max8(rk8[k] != 0u ? (fx & 7u) : 0u);
-#pragma unroll
-                            for (int j = 0; j < PGM_KX; ++j) {
-                                if (j < nxk) {
-                                    const float W2 = *(const float *)(hWb + (((tk8 - cj8[j]) & MW) | lk4[k]));
-                                    Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W2, S), cyv[k]), cxv[j]));
-                                }
-                            }
-                        }
-                    }
-                    if (!overflow) { Mv = fmaxf(Mv, Mn); Xv = fmaxf(Xv, Xn); Yv = fmaxf(Yv, Yn); }
-                }
-                // ---- far / many predecessors: every non-chain pair from the cell storage (HBM/L2) ---------------
-                const bool gen = active && (geny || genx || overflow);
-                if (__builtin_amdgcn_ballot_w64(gen) != 0) {
-                    if (gen) {
-                        const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
-                        for (uint32_t e = xby; e < xey; ++e) {
-                            const uint32_t yp = J.xc1[e];
-                            const float cy = J.xv1[e];
-                            const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
-                            Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
-                            if (x > 0) {
-                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x - 1));
-                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
-                            }
-                            for (uint32_t f = xbx; f < xex; ++f) {
-                                const uint32_t xp = J.xc2[f];
-                                const float cx = J.xv2[f];
-                                const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
-                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
-                            }
-                        }
-                        for (uint32_t f = xbx; f < xex; ++f) {
-                            const uint32_t xp = J.xc2[f];
-                            const float cx = J.xv2[f];
-                            const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
-                            const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
-                            Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
-                            if (y > 0) {
-                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, y - 1, xp));
-                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), ccy), cx));
-                            }
-                        }
-                    }
-                }
-                if (ykill) Xv = PGM_NEG_INF;  // interior row without predecessors: the pair loop never runs
-                if (xkill) Yv = PGM_NEG_INF;
-                float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
-                if (rowvalid && y == 0 && xs == 0) Wv = s_init;  // GraphAlign.h:212
-                if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
-                if (!comp) {
-                    // replay lane: the values band b-1 computed for this cell
-                    const float2 rv = rep[i * HR + (lane & (HR - 1))];
-                    Wv = incol ? rv.x : PGM_NEG_INF;
-                    Yv = incol ? rv.y : PGM_NEG_INF;
-                }
-                if (active) {
-                    pgm_store_cell<DUMMY>(cells_rsrc, t, lane, Mv, Xv, Wv, Yv);
-                    W_left = Wv;
-                    X_left = Xv;
-                }
-                {
-                    const int ho = (int)((t & (H - 1)) << 6) + lane;
-                    hW[(int)((t & (HW - 1)) << 6) + lane] = Wv;
-                    hY[ho] = Yv;
-                    hX[ho] = Xv;
-                }
-                W_diag = W_up;
-                W_o = Wv;
-                Y_o = Yv;
-            }
-            const unsigned long long c2 = (DUMMY == 4) ? __builtin_readcyclecounter() : 0ull;
-            // publish: the youngest BL vector-memory operations of this wavefront are this block's cell stores; once
-            // all older ones have retired, every (write-through) cell store of the blocks before this one is in memory.
-            if (has_next) {
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
-                if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (DUMMY == 4) { const unsigned long long c3 = __builtin_readcyclecounter(); cyc_a += c1 - c0; cyc_b += c2 - c1; cyc_c += c3 - c2; cyc_w += cw1 - cw0; }
-        }
-        if (DUMMY == 4 && lane == 0) {
-            const uint32_t nblocks = tsteps / BL;
-            J.map1[4 * b + 0] = (uint32_t)(cyc_a / nblocks); J.map1[4 * b + 1] = (uint32_t)(cyc_w / nblocks);
-            J.map1[4 * b + 2] = (uint32_t)(cyc_b / nblocks); J.map1[4 * b + 3] = (uint32_t)(cyc_c / nblocks);
-        }
-        // band complete (the last band's counter is what the concurrently launched traceback workgroup of this job waits for)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Fill kernel with helper wavefronts (used when a batch contains merged graphs, i.e. skip-edge predecessors).
-//
-// Same band sweep as pgm_fill_kernel, but a worker is a 256-thread workgroup: wavefront 0 ("main") owns the band's
-// dependency chain (chain predecessors, cell store, history, hand-off to the next band); wavefronts 1..3 ("helpers")
-// evaluate the skip-edge terms.  This works because every skip-edge term of step t only needs history up to step
-// t-2 (an extra predecessor is at least 2 nodes back): the helpers compute the terms of step t while the main
-// wavefront is still finishing steps t-2 and t-1, so the ~300 instructions of the skip-edge path leave the band's
-// critical path and the main wavefront's step shrinks to the chain recurrence plus five LDS reads.
-//   helper 1: column extras (X terms, M terms with the chain row)
-//   helper 2: row extras (Y terms, M terms with the chain column) and the pairs of the first row extra
-//   helper 3: the pairs of the other row extras
-// Hand-shake through LDS counters (workgroup-scope release/acquire): main_done = last step whose history is written,
-// help_done[h] = last step whose partial maxima are in `res`.  res has four step slots; the ring of column summaries
-// and the emission scores are stored one block earlier than in the single-wavefront kernel (helpers run up to two
-// steps ahead of the main wavefront), so they are loaded two blocks ahead and the scores are double buffered.
-template <int DUMMY>
-__global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict__ jobs, const PgmWorker *__restrict__ workers,
-                                                       int *__restrict__ abort_flag) {
+__global__ void __launch_bounds__(256) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
+                                                      int *__restrict__ sync) {
+    int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
     constexpr int NQ = 4;
     constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
     constexpr int PFQ = (BL * NQ + 63) / 64;
-    constexpr int NH = 3;
     __shared__ __attribute__((aligned(16))) float4 ring[R * NQ];
     __shared__ float hW[HW * 64];
     __shared__ float hY[H * 64];
     __shared__ float hX[H * 64];
     __shared__ float2 rep[BL * HR];
     __shared__ float sblk[2 * BL * 64];
-    __shared__ float res1[4 * 2 * 64];     // [step & 3][M, X][lane]: partial maxima of helper 1 (plain stores)
-    __shared__ float resA[4 * 2 * 64];     // [step & 3][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
+    __shared__ float res1[2 * 2 * 64];     // [step & 1][M, X][lane]: partial maxima of helper 1 (plain stores)
+    __shared__ float resA[2 * 2 * 64];     // [step & 1][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
     __shared__ uint32_t el_a[PGM_ENT];     // row-extra entries of the band: distance << 8 | owner lane
     __shared__ float el_c[PGM_ENT];        //                                 edge cost
     __shared__ uint32_t ovf[64];           // rows whose entries did not fit (they take the generic path)
     __shared__ int el_cnt;
-    __shared__ __attribute__((aligned(16))) int help_done[4];   // last step each helper has finished (read with one 16-byte LDS load)
-    __shared__ int main_done, lds_abort;
+    __shared__ int lds_abort, item_lds;
 
-    const PgmWorker wk = workers[blockIdx.x];
-    const PgmJob &J = jobs[wk.job];
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
-    const bool need_help = J.has_extras != 0;
-    if (role != 0 && !need_help) return;     // chain-only job: the main wavefront alone (no barriers are used then)
-    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
-    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
     bool aborted = false;
+    // One hardware barrier per step keeps the four wavefronts in lock step ("tick"): only LDS traffic has to be
+    // complete at the barrier, the cell stores in flight are not waited for (a plain __syncthreads() would drain them).
+    auto tick = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
     if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (uint32_t b = wk.rank; b < nb && !aborted; b += wk.nworkers) {
+    for (;;) {
+        // next band of the list (all four wavefronts take the same one)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int it = -1;
+            if (!aborted && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
+        }
+        __syncthreads();
+        const int it = item_lds;
+        if (it < 0) break;
+        const PgmItem item = items[it];
+        const PgmJob &J = jobs[item.job];
+        const uint32_t b = item.band;
+        const bool need_help = J.has_extras != 0;
+        if (role != 0 && !need_help) continue;     // chain-only job: the main wavefront alone (no barriers inside the band)
+        const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
+        const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
         const bool comp = lane >= HR;
         const uint32_t y = RC * b + (uint32_t)(lane - HR);
         const bool rowvalid = comp && y + 1 < n1;
@@ -686,10 +360,9 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
         if (role == 0) {
             for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
             for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
-            for (int i = lane; i < 4 * 2 * 64; i += 64) resA[i] = PGM_NEG_INF;
+            for (int i = lane; i < 2 * 2 * 64; i += 64) resA[i] = PGM_NEG_INF;
             if (lane == 0) {
-                main_done = -1; lds_abort = 0;
-                help_done[0] = -1; help_done[1] = -1; help_done[2] = -1; help_done[3] = 0x7fffffff;
+                lds_abort = 0;
             }
         } else if (role == 2) {
             // Row-extra entry list of this band (order irrelevant): each row appends its extras at a position taken from
@@ -811,6 +484,7 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             float2 aux_n = *(const float2 *)(ring + xr * NQ), rep_n = make_float2(PGM_NEG_INF, PGM_NEG_INF);   // operands of step 0
             float S_n = sblk[lane];
             const unsigned long long mc_start = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+            uint32_t ticks = 0;
             for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
                 if (t0 > 0) {
                     store_ring_block(t0 + BL);     // one block before use (helpers run ahead of this wavefront)
@@ -852,25 +526,16 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     float Yv = __fsub_rn(fmaxf(__fadd_rn(Y_up, ge), __fadd_rn(W_up, gopen_y)), ccy);
                     const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
                     if (need_help) {
-                        // partial maxima of the helpers for this step
+                        // tick t: the helpers have finished the partial maxima of step t (and start on step t + 1, which
+                        // needs the history up to step t - 1, complete since the previous iteration)
                         const unsigned long long mc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-                        // One LDS round trip in the common case: the counter and the partials are read together; LDS
-                        // executes a wavefront's operations in order, so partials read after a complete counter are final.
-                        const float *r1 = res1 + (t & 3u) * (2 * 64) + lane;
-                        float *ra = resA + (t & 3u) * (2 * 64) + lane;
-                        float m1, x1, m2, y2;
-                        uint32_t spins = 0;
-                        for (;;) {
-                            asm volatile("" ::: "memory");
-                            const int4 hd = *(const int4 *)help_done;
-                            asm volatile("" ::: "memory");
-                            m1 = r1[0]; x1 = r1[64]; m2 = ra[0]; y2 = ra[64];
-                            asm volatile("" ::: "memory");
-                            if (min(min(hd.x, hd.y), hd.z) >= (int)t) break;
-                            if (++spins > PGM_SPIN_LIMIT) { aborted = true; break; }
-                        }
+                        tick();
+                        ++ticks;
                         if (DUMMY & 8) mcyc_wait += __builtin_readcyclecounter() - mc0;
-                        ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 4
+                        const float *r1 = res1 + (t & 1u) * (2 * 64) + lane;
+                        float *ra = resA + (t & 1u) * (2 * 64) + lane;
+                        const float m1 = r1[0], x1 = r1[64], m2 = ra[0], y2 = ra[64];
+                        ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 2
                         if (!overflow) {
                             Mv = fmaxf(Mv, fmaxf(m1, m2));
                             Xv = fmaxf(Xv, x1);
@@ -933,10 +598,6 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     W_diag = W_up;
                     W_o = Wv;
                     Y_o = Yv;
-                    if (need_help) {
-                        asm volatile("" ::: "memory");   // LDS executes in order: the history writes above precede this flag
-                        if (lane == 0) __hip_atomic_store(&main_done, (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
                 }
                 if (has_next) {
                     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
@@ -944,7 +605,11 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                 }
             }
             if ((DUMMY & 8) && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
-            if (need_help && aborted && lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (need_help && aborted) {
+                // a hand-off timed out: tell the helpers (read after the band's last barrier) and serve the remaining ticks
+                if (lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (const uint32_t tend = (tsteps + BL - 1) / BL * BL; ticks < tend; ++ticks) tick();
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -953,15 +618,6 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
             const int h = role - 1;
             const uint32_t tend = (tsteps + BL - 1) / BL * BL;   // the main wavefront always finishes its last block
             unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-            // history up to step t-2 must be in place before the history reads of step t
-            auto wait_main = [&](uint32_t t) -> bool {
-                uint32_t spins = 0;
-                while (__hip_atomic_load(&main_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)t - 2) {
-                    if (__hip_atomic_load(&lds_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 || ++spins > PGM_SPIN_LIMIT) return false;
-                }
-                asm volatile("" ::: "memory");
-                return true;
-            };
             if (h == 0) {
                 // ---- helper 1: column extras, one row per lane like the main wavefront -----------------------------
                 for (uint32_t t = 0; t < tend; ++t) {
@@ -977,14 +633,13 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     float cxv[PGM_KX];
                     if (nxw > 0) load_cols(rc, aux, cj8, cxv);
                     const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-                    if (!wait_main(t)) break;
                     const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     if (!(DUMMY & 1) && nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
-                    float *rs = res1 + (t & 3u) * (2 * 64) + lane;
+                    float *rs = res1 + (t & 1u) * (2 * 64) + lane;
                     rs[0] = Mn; rs[64] = Xn;
-                    asm volatile("" ::: "memory");   // in-order LDS: the partials above precede the flag
-                    if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc1 - hc0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb + (hc1 - hc0) * 0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             } else {
                 // ---- helpers 2 and 3: one ROW EXTRA (entry) per lane -----------------------------------------------
@@ -1042,10 +697,9 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                     }
                     const bool work = __builtin_amdgcn_ballot_w64(any) != 0;
                     const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-                    if (!wait_main(t)) break;
                     const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     if (work && !(DUMMY & (h == 1 ? 2 : 4))) {
-                        float *ra = resA + (t & 3u) * (2 * 64);
+                        float *ra = resA + (t & 1u) * (2 * 64);
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             if (p == 0 || two) {
@@ -1070,14 +724,17 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel4(const PgmJob *__restrict
                             }
                         }
                     }
-                    asm volatile("" ::: "memory");   // in-order LDS: the partials above precede the flag
-                    if (lane == 0) __hip_atomic_store(&help_done[h], (int)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc1 - hc0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb + (hc1 - hc0) * 0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             }
             if ((DUMMY & 8) && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
         }
-        if (need_help) __syncthreads();   // band finished: nobody reads the history any more
+        if (need_help) {
+            __syncthreads();   // band finished: nobody reads the history any more
+            if (lds_abort != 0) aborted = true;
+        }
     }
 }
 
@@ -1157,7 +814,8 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 // next PGM_TB_AHEAD anti-diagonals the walk can reach, so that the walker's dependent loads hit L2 instead of HBM
 // (the walk is a pointer chase: one cell decides which cell is read next).
 #define PGM_TB_AHEAD 48
-__global__ void __launch_bounds__(128) pgm_traceback_kernel(const PgmJob *__restrict__ jobs, int *__restrict__ abort_flag) {
+// (56 VGPRs: the traceback workgroups must fit next to three resident fill workers per CU, 3 x 152 + 56 = 512 per SIMD lane)
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_num_vgpr(56))) pgm_traceback_kernel(const PgmJob *__restrict__ jobs, int *__restrict__ abort_flag) {
     const PgmJob &J = jobs[blockIdx.x];
     const int lane = threadIdx.x;
     __shared__ int s_abort;

@@ -70,11 +70,11 @@ struct pgm_align_batch {
     uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
     std::vector<uint8_t> h_out;
     uint8_t *d_S = nullptr;           // emission scores in fill order
-    int *d_sync = nullptr;            // [0] abort flag, then the per-band progress counters of every job
+    int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
     size_t sync_ints = 0, s_bytes = 0;
-    PgmWorker *d_workers = nullptr;
+    PgmItem *d_items = nullptr;       // band list of the batch (fill work queue)
+    uint32_t nitems = 0;
     uint32_t nworkers = 0, maxnblk = 0;
-    bool any_extras = false, use_helpers = false;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
     size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0, out_bytes = 0;
@@ -228,23 +228,10 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // so the walks of all small jobs overlap the fill of the large ones.
     if ((e = hipEventRecord(ctx->ev_ready, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0)) != hipSuccess) return e;
-    const char *dbg = getenv("PGM_FILL_DBG");
+    const char *dbg = getenv("PGM_FILL_DBG");   // 8: cycle-counter build of the fill kernel (tools/probe_cyc.py), no traceback
     const int dbgv = dbg ? atoi(dbg) : 0;
-    if (0) {}
-    else if (b->use_helpers && dbgv == 1) hipLaunchKernelGGL((pgm_fill_kernel4<1>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 2) hipLaunchKernelGGL((pgm_fill_kernel4<2>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 3) hipLaunchKernelGGL((pgm_fill_kernel4<3>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 4) hipLaunchKernelGGL((pgm_fill_kernel4<4>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 5) hipLaunchKernelGGL((pgm_fill_kernel4<5>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 6) hipLaunchKernelGGL((pgm_fill_kernel4<6>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 7) hipLaunchKernelGGL((pgm_fill_kernel4<7>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers && dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel4<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (b->use_helpers) hipLaunchKernelGGL((pgm_fill_kernel4<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (dbgv == 1) hipLaunchKernelGGL((pgm_fill_kernel<1>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (dbgv == 2) hipLaunchKernelGGL((pgm_fill_kernel<2>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (dbgv == 3) hipLaunchKernelGGL((pgm_fill_kernel<3>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else if (dbgv == 4) hipLaunchKernelGGL((pgm_fill_kernel<4>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
-    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(64), 0, s, b->d_jobs, b->d_workers, b->d_sync);
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync);
+    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (dbgv == 0) hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, ctx->stream2, b->d_jobs, b->d_sync);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -268,9 +255,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->jobs.resize(njobs);
     Arena A;
     DevLayout W, C, O, SL;
-    size_t sync_ints = 4;   // [0] abort flag (+ padding to 16 B)
+    size_t sync_ints = 4;   // [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
     std::vector<size_t> prog_off(njobs), s_off(njobs);
-    std::vector<double> extras_frac(njobs, 0.0);
     struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
@@ -299,9 +285,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             delete b;
             return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
         }
-        extras_frac[i] = 0.5 * ((double)o.s1.nodes_with_extras / a->n + (double)o.s2.nodes_with_extras / c->n);
         J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
-        b->any_extras |= J.has_extras != 0;
         o.M = A.put(model[i]->M, sizeof(double) * a->dim * a->dim);
         o.pi = A.put(model[i]->pi, sizeof(double) * a->dim);
         o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
@@ -361,65 +345,39 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) {
         return (uint64_t)b->jobs[x].n1 * b->jobs[x].n2 > (uint64_t)b->jobs[y].n1 * b->jobs[y].n2;
     });
-    // ---- fill workers: one wavefront each, all co-resident (4 per CU), shared out in proportion to the
-    // wave-steps of each job (largest job first so that its workers are dispatched first)
-    std::vector<PgmWorker> workers;
+    // ---- fill work list: every band of every job, longest remaining path first.  The remaining path of band b is
+    // the time until its job is complete once the band can start: the (nb-1-b) band-to-band lags still ahead plus one
+    // full sweep, at the job's step time (chain-only jobs: the main wavefront alone, ~0.38 us; merged graphs: lock-step
+    // with the helper wavefronts, ~0.65 us).  Within a job the order is band 0, 1, 2, ... as the kernel requires.
+    std::vector<PgmItem> items;
     if (njobs) {
-        // helper-wavefront kernel (4 wavefronts, 39 KB LDS per worker): 3 workers per CU; single-wavefront kernel: 4 per CU
-        const char *env_h = getenv("PGM_FILL_HELPERS");
-        b->use_helpers = (b->any_extras && !(env_h && env_h[0] == '0')) || (env_h && env_h[0] == '2');   // 0 / 2: experiments (never / always)
-        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * (b->use_helpers ? 3u : 4u);
-        if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
-        // Makespan-greedy: a job swept by W workers takes about (ceil(nb/W) * tsteps + (min(W,nb)-1) * lag) steps of
-        // cost tau, tau growing with the share of nodes that carry skip-edge predecessors (measured: 0.4 us/step
-        // for chains, 2.2 us/step at 60 %).  Every worker goes to the job that currently finishes last.
-        std::vector<uint32_t> wj(njobs, 1);
-        uint64_t bands = 0;
-        for (uint32_t i = 0; i < njobs; ++i) bands += b->jobs[i].nb;
-        const uint32_t budget = (uint32_t)std::min<uint64_t>(capacity, bands);
-        if (budget > njobs) {
-            const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
-            std::vector<double> tau(njobs);
-            for (uint32_t i = 0; i < njobs; ++i) tau[i] = 1.0 + 7.5 * extras_frac[i];
-            auto est = [&](uint32_t i, uint32_t w) {
-                const PgmJob &J = b->jobs[i];
-                const uint32_t rounds = (J.nb + w - 1) / w;
-                return tau[i] * ((double)rounds * J.tsteps + (double)(std::min(w, J.nb) - 1) * lag);
-            };
-            std::vector<std::pair<double, uint32_t>> heap;
-            for (uint32_t i = 0; i < njobs; ++i) heap.push_back({est(i, 1), i});
-            std::make_heap(heap.begin(), heap.end());
-            uint32_t used = njobs;
-            while (used < budget && !heap.empty()) {
-                std::pop_heap(heap.begin(), heap.end());
-                const uint32_t i = heap.back().second;
-                heap.pop_back();
-                if (wj[i] >= b->jobs[i].nb) continue;   // cannot use more workers than bands
-                // jump to the next worker count that actually lowers the number of rounds
-                uint32_t w = wj[i] + 1;
-                const uint32_t rounds = (b->jobs[i].nb + wj[i] - 1) / wj[i];
-                while (w < b->jobs[i].nb && (b->jobs[i].nb + w - 1) / w == rounds) ++w;
-                if (used + (w - wj[i]) > budget) continue;
-                used += w - wj[i];
-                wj[i] = w;
-                heap.push_back({est(i, w), i});
-                std::push_heap(heap.begin(), heap.end());
-            }
+        struct Key { double rem; uint32_t job, band; };
+        std::vector<Key> keys;
+        const double lag = PGM_ROWS + 4.0 * PGM_BLOCK;
+        for (uint32_t i = 0; i < njobs; ++i) {
+            const PgmJob &J = b->jobs[i];
+            const double tau = J.has_extras ? 0.65 : 0.38;
+            for (uint32_t band = 0; band < J.nb; ++band) keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps), i, band});
         }
-        for (uint32_t k = 0; k < njobs; ++k) {
-            const uint32_t i = b->order[k];
-            for (uint32_t r = 0; r < wj[i]; ++r) workers.push_back(PgmWorker{i, r, wj[i], 0});
-        }
+        std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.rem > y.rem; });
+        items.reserve(keys.size());
+        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band});
     }
-    b->nworkers = (uint32_t)workers.size();
-    if ((e = hipMalloc((void **)&b->d_workers, sizeof(PgmWorker) * std::max<size_t>(1, workers.size()))) != hipSuccess) {
+    b->nitems = (uint32_t)items.size();
+    {
+        // persistent workers: 3 workgroups of 4 wavefronts per CU (150 VGPRs, 40 KB LDS each)
+        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 3u;
+        if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
+        b->nworkers = std::max(1u, std::min(capacity, b->nitems));
+    }
+    if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     if ((e = hipMemcpyAsync(b->d_in, A.host.data(), A.host.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(b->d_workers, workers.data(), sizeof(PgmWorker) * workers.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
@@ -499,7 +457,7 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (b->d_out) (void)hipFree(b->d_out);
     if (b->d_S) (void)hipFree(b->d_S);
     if (b->d_sync) (void)hipFree(b->d_sync);
-    if (b->d_workers) (void)hipFree(b->d_workers);
+    if (b->d_items) (void)hipFree(b->d_items);
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_order) (void)hipFree(b->d_order);
     delete b;

@@ -89,10 +89,10 @@ struct PgmJob {
 };
 
 
-// One fill worker = one wavefront (a 64-thread workgroup).  Job `job` is swept by `nworkers` workers;
-// worker `rank` takes the bands rank, rank + nworkers, ...
-struct PgmWorker {
-    uint32_t job, rank, nworkers, pad;
+// One unit of fill work: band `band` (48 rows) of job `job`.  The list is ordered so that band b of a job comes after
+// band b-1 (workers take the bands in list order, see pgm_fill_kernel).
+struct PgmItem {
+    uint32_t job, band;
 };
 
 #endif
