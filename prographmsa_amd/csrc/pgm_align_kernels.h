@@ -207,6 +207,353 @@ __device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y
     return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Traceback (GraphAlign.h:264-521), run by the fill worker that completes a job's last band (all cells of the job are
+// then written through to memory).  Thread 0 walks END -> START with the reference's tie rules (smallest
+// |current - recomputed|, first candidate in PredIterator order wins, extension tested before opening, state after a
+// W source chosen by equality in the order M, Y, X).  The walk is a pointer chase (one cell decides which cell is
+// read next), so the whole workgroup stages a 32 x 32 TILE of cells, emission scores and predecessor lists around the
+// walker's position in LDS; the walker then reads LDS (~100 cycles) instead of L2/HBM (~1000 cycles) per dependent
+// access and asks for a new tile when it gets within PGM_TB_MARGIN rows or columns of the tile's low edge.  Anything
+// outside the tile (far skip / repeat edges, nodes with more than 8 predecessors) is read from memory as before.
+struct PgmPred {
+    const int32_t *pp; const uint32_t *pc; const float *pv; const uint32_t *pu;
+};
+__device__ __forceinline__ float pgm_mark_value(const PgmPred &P, int32_t e) {
+    // value() with repeat_init = repeat_ext = +inf (markAlternativePath, GraphAlign.h:174)
+    const uint32_t u = P.pu[e];
+    if (u == 0) return P.pv[e];
+    const uint32_t units = u & 0x7fffffffu;
+    if (units == 0) return INFINITY;
+    return __fadd_rn(INFINITY, __fmul_rn(INFINITY, (float)(units - 1)));
+}
+
+struct PgmMapOut {
+    uint32_t *m1, *m2;
+    uint32_t len, cap;
+    __device__ __forceinline__ void push(uint32_t y, uint32_t x) {
+        if (len < cap) { m1[len] = y; m2[len] = x; }
+        ++len;
+    }
+};
+
+__device__ static void pgm_mark_alternative_path(const PgmJob &J, uint32_t start, uint32_t end, const PgmPred &P, PgmMapOut &mo, bool first) {
+    const uint32_t len = end - start + 1;
+    float *score = J.mark_score;
+    uint32_t *prev = J.mark_prev;
+    for (uint32_t i = 0; i < len; ++i) { score[i] = PGM_NEG_INF; prev[i] = 0xFFFFFFFFu; }
+    score[0] = 0.0f;
+    for (uint32_t i = 1; i < len; ++i) {
+        const uint32_t real_ix = i + start;
+        for (int32_t e = P.pp[real_ix]; e < P.pp[real_ix + 1]; ++e) {
+            const uint32_t p = P.pc[e];
+            if (p >= start && p <= end) {
+                const uint32_t i2 = p - start;
+                const float cand = __fsub_rn(score[i2], pgm_mark_value(P, e));
+                if (score[i] <= cand) { score[i] = cand; prev[i] = i2; }
+            }
+        }
+    }
+    if (score[len - 1] > PGM_NEG_INF) {
+        uint32_t i = prev[len - 1];
+        while (i != 0) {
+            if (first) mo.push(i + start, 0xFFFFFFFFu); else mo.push(0xFFFFFFFFu, i + start);
+            i = prev[i];
+        }
+    }
+}
+
+// S(y,x) as the emission kernel stored it (skewed order, see PgmJob::S): one load instead of recomputing the dot product
+__device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, uint32_t x) {
+    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS), t = x + l;
+    return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
+}
+
+#define PGM_TB_T 32        // tile edge (rows and columns)
+#define PGM_TB_MARGIN 8    // a new tile is staged when the walker is closer than this to the tile's low edge
+#define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
+struct PgmTbLds {
+    float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
+    float S[PGM_TB_T * PGM_TB_T];
+    uint32_t p_cnt[2 * PGM_TB_T];              // slots 0..T-1: rows ty0.. of graph 1; T..2T-1: columns tx0.. of graph 2
+    uint32_t p_c[2 * PGM_TB_T * PGM_TB_PK];    // predecessor node, PredIterator order
+    float p_v[2 * PGM_TB_T * PGM_TB_PK];       // edge value
+    uint32_t p_u[2 * PGM_TB_T * PGM_TB_PK];    // repeat marker
+    uint32_t ty0, tx0;                         // tile origin
+    int req;                                   // 1: stage a tile at (ty0, tx0); 2: walk finished
+    uint32_t len;
+};
+
+// predecessor list of one node: either in the tile (LDS) or in memory
+struct PgmPredView {
+    uint32_t cnt;
+    bool lds;
+    uint32_t base;     // LDS: slot * PGM_TB_PK; memory: first entry index
+};
+
+__device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads) {
+    constexpr uint32_t TT = PGM_TB_T;
+    const uint32_t n1 = J.n1, n2 = J.n2;
+    const PgmPred P1 = {J.pp1, J.pc1, J.pv1, J.pu1};
+    const PgmPred P2 = {J.pp2, J.pc2, J.pv2, J.pu2};
+
+    // ---- tile staging: wavefronts 1.. (a barrier is per wavefront, so the walker's wavefront 0 cannot also be a loader:
+    // its lanes 1..63 simply sit out the walk) ----------------------------------------------------------------------
+    const bool loader = tid >= 64;
+    const uint32_t ltid = (uint32_t)(tid - 64), nload = (uint32_t)(nthreads - 64);
+    auto stage = [&]() {
+        const uint32_t ty0 = T.ty0, tx0 = T.tx0;
+        for (uint32_t i = ltid; i < TT * TT; i += nload) {
+            const uint32_t yy = ty0 + i / TT, xx = tx0 + i % TT;
+            if (yy + 1 < n1 && xx + 1 < n2) {
+                T.cell[i] = J.cells[pgm_cell_index(J, yy, xx)];
+                T.S[i] = pgm_emission_at(J, yy, xx);
+            }
+        }
+        for (uint32_t i = ltid; i < 2 * TT * PGM_TB_PK; i += nload) {
+            const uint32_t slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const bool row = slot < TT;
+            const uint32_t v = row ? ty0 + slot : tx0 + (slot - TT);
+            const PgmPred &P = row ? P1 : P2;
+            if (v < (row ? n1 : n2)) {
+                const int32_t eb = P.pp[v], ee = P.pp[v + 1];
+                const uint32_t cnt = (uint32_t)(ee - eb);
+                if (k == 0) T.p_cnt[slot] = cnt;
+                if (k < cnt && cnt <= PGM_TB_PK) { T.p_c[i] = P.pc[eb + k]; T.p_v[i] = P.pv[eb + k]; T.p_u[i] = P.pu[eb + k]; }
+            } else if (k == 0) {
+                T.p_cnt[slot] = 0xFFFFFFFFu;
+            }
+        }
+    };
+    if (tid == 0) {
+        T.ty0 = n1 - 2 >= TT - 1 ? n1 - 2 - (TT - 1) : 0u;
+        T.tx0 = n2 - 2 >= TT - 1 ? n2 - 2 - (TT - 1) : 0u;
+        T.req = 1;
+    }
+    __syncthreads();
+    if (loader) stage();
+    __syncthreads();
+
+    if (loader) {
+        // ---- loaders (wavefronts 1..): serve the walker's tile requests ----
+        for (;;) {
+            __syncthreads();            // request posted
+            if (T.req == 2) break;
+            stage();
+            __syncthreads();            // tile staged
+        }
+    } else {
+        // ---- walker: wavefront 0, uniform control flow; the one-off END step is evaluated by lane 0 alone ----
+        const int lane = tid;
+        const pgm_scores s = J.sc;
+        uint32_t ty0 = T.ty0, tx0 = T.tx0;
+        auto in_tile = [&](uint32_t y, uint32_t x) { return (y - ty0) < TT && (x - tx0) < TT; };
+        auto cell_at = [&](uint32_t y, uint32_t x) -> float4 {
+            if (in_tile(y, x)) return T.cell[(y - ty0) * TT + (x - tx0)];
+            return pgm_load_cell(J, y, x);
+        };
+        auto s_at = [&](uint32_t y, uint32_t x) -> float {
+            if (in_tile(y, x)) return T.S[(y - ty0) * TT + (x - tx0)];
+            return pgm_emission_at(J, y, x);
+        };
+        auto preds = [&](bool row, uint32_t v) -> PgmPredView {
+            const uint32_t slot = row ? v - ty0 : (v - tx0) + TT;
+            if ((row ? v - ty0 : v - tx0) < TT) {
+                const uint32_t cnt = T.p_cnt[slot];
+                if (cnt <= PGM_TB_PK) return PgmPredView{cnt, true, slot * PGM_TB_PK};
+            }
+            const PgmPred &P = row ? P1 : P2;
+            const int32_t eb = P.pp[v];
+            return PgmPredView{(uint32_t)(P.pp[v + 1] - eb), false, (uint32_t)eb};
+        };
+        auto pc_of = [&](bool row, const PgmPredView &V, uint32_t k) { return V.lds ? T.p_c[V.base + k] : (row ? P1 : P2).pc[V.base + k]; };
+        auto pv_of = [&](bool row, const PgmPredView &V, uint32_t k) { return V.lds ? T.p_v[V.base + k] : (row ? P1 : P2).pv[V.base + k]; };
+        auto pu_of = [&](bool row, const PgmPredView &V, uint32_t k) { return V.lds ? T.p_u[V.base + k] : (row ? P1 : P2).pu[V.base + k]; };
+
+        int status = PGM_OK;
+        uint32_t n_tr = 0;
+        enum { State_m = 0, State_x = 1, State_y = 2 };
+        int current_state = State_m;
+        float current_score = PGM_NEG_INF, Wend = PGM_NEG_INF;
+        uint32_t y = n1 - 1, x = n2 - 1;
+        PgmMapOut mo = {J.map1, J.map2, 0u, n1 + n2};
+        if (lane == 0) {
+            // end node (GraphAlign.h:264-280)
+            const PgmPredView Ey = preds(true, n1 - 1), Ex = preds(false, n2 - 1);
+            for (uint32_t ky = 0; ky < Ey.cnt; ++ky) {
+                for (uint32_t kx = 0; kx < Ex.cnt; ++kx) {
+                    const uint32_t yp = pc_of(true, Ey, ky), xp = pc_of(false, Ex, kx);
+                    const float yv = pv_of(true, Ey, ky), xv = pv_of(false, Ex, kx);
+                    if (xp == 0 && yp == 0) {
+                        Wend = fmaxf(__fsub_rn(__fsub_rn(s.end_skip, yv), xv), Wend);
+                    } else {
+                        const float4 c = cell_at(yp, xp);
+                        Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv), Wend);
+                        Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv), Wend);
+                        Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv), Wend);
+                    }
+                }
+            }
+            mo.push(n1 - 1, n2 - 1);
+            bool tr_x = false, tr_y = false;
+            float best = INFINITY;
+            for (uint32_t ky = 0; ky < Ey.cnt; ++ky) {
+                for (uint32_t kx = 0; kx < Ex.cnt; ++kx) {
+                    const uint32_t yp = pc_of(true, Ey, ky), xp = pc_of(false, Ex, kx);
+                    const float yv = pv_of(true, Ey, ky), xv = pv_of(false, Ex, kx);
+                    const bool ry = pu_of(true, Ey, ky) != 0, rx = pu_of(false, Ex, kx) != 0;
+                    const float4 c = cell_at(yp, xp);
+                    float d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv)));
+                    if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.x; current_state = State_m; y = yp; x = xp; }
+                    d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv)));
+                    if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.w; current_state = State_y; y = yp; x = xp; }
+                    d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv)));
+                    if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.y; current_state = State_x; y = yp; x = xp; }
+                    d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(s.end_skip, yv), xv)));
+                    if (xp == 0 && yp == 0 && best > d) { best = d; tr_x = rx; tr_y = ry; y = yp; x = xp; }
+                }
+            }
+            n_tr += (uint32_t)tr_x + (uint32_t)tr_y;
+            if (tr_y) pgm_mark_alternative_path(J, y, n1 - 1, P1, mo, true);
+            if (tr_x) pgm_mark_alternative_path(J, x, n2 - 1, P2, mo, false);
+            if (x != 0 || y != 0) {
+                if (current_state == State_m) mo.push(y, x);
+                else if (current_state == State_x) mo.push(0xFFFFFFFFu, x);
+                else mo.push(y, 0xFFFFFFFFu);
+            }
+        }
+        // lane 0's result becomes the wavefront's (uniform) walker state
+        y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x);
+        current_state = __builtin_amdgcn_readfirstlane(current_state);
+        current_score = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(current_score)));
+        Wend = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Wend)));
+        n_tr = __builtin_amdgcn_readfirstlane(n_tr);
+        mo.len = __builtin_amdgcn_readfirstlane(mo.len);
+
+        // ---- the walk: every candidate predecessor of the current cell is evaluated by its own lane --------------------
+        // Lane order = PredIterator order (row predecessor outer, column predecessor inner; in the gap states extension
+        // before opening), so "first candidate with the smallest |current - recomputed|" is the first lane holding the
+        // minimum.  In a consistent DP the producing candidate recomputes the stored value exactly (difference 0), which
+        // one ballot finds; only if no lane is exact the minimum is searched lane by lane.
+        auto rl_u = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
+        auto rl_f = [](float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+        uint32_t guard = 0;
+        while ((x != 0 || y != 0) && status == PGM_OK) {
+            if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
+            // new tile when the walker is near the low edge of the current one (or outside it, after a far edge)
+            if (((y - ty0) >= TT || ((y - ty0) < PGM_TB_MARGIN && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < PGM_TB_MARGIN && tx0 != 0))) {
+                ty0 = y >= TT - 1 ? y - (TT - 1) : 0u;
+                tx0 = x >= TT - 1 ? x - (TT - 1) : 0u;
+                if (lane == 0) { T.ty0 = ty0; T.tx0 = tx0; T.req = 1; }
+                __syncthreads();        // request posted
+                __syncthreads();        // tile staged
+            }
+            const bool need_y = current_state != State_x, need_x = current_state != State_y;
+            PgmPredView Vy = {1u, false, 0u}, Vx = {1u, false, 0u};
+            if (need_y) Vy = preds(true, y);
+            if (need_x) Vx = preds(false, x);
+            const float S = (current_state == State_m) ? s_at(y, x) : 0.0f;
+            // candidates: state M: (ky, kx) pairs; state Y / X: (k, extend | open)
+            const uint32_t per = (current_state == State_m) ? Vx.cnt : 2u;
+            const uint32_t total = (current_state == State_m) ? Vy.cnt * Vx.cnt : 2u * (need_y ? Vy.cnt : Vx.cnt);
+            float best = INFINITY;
+            uint32_t w_yp = 0xFFFFFFFFu, w_xp = 0xFFFFFFFFu, w_uy = 0, w_ux = 0, w_kind = 0;
+            float4 w_c = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool found = false;
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t i = base + (uint32_t)lane;
+                const bool valid = i < total;
+                const uint32_t ka = valid ? i / per : 0u, kb = valid ? i % per : 0u;   // (ky, kx) or (k, kind)
+                uint32_t yp = y, xp = x, uy = 0, ux = 0;
+                float yv = 0.0f, xv = 0.0f;
+                if (need_y) { const uint32_t k = ka; if (valid) { yp = pc_of(true, Vy, k); yv = pv_of(true, Vy, k); uy = pu_of(true, Vy, k); } }
+                if (need_x) { const uint32_t k = (current_state == State_m) ? kb : ka; if (valid) { xp = pc_of(false, Vx, k); xv = pv_of(false, Vx, k); ux = pu_of(false, Vx, k); } }
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) c = cell_at(yp, xp);
+                float d;
+                if (current_state == State_m) d = fabsf(__fsub_rn(current_score, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
+                else if (current_state == State_y) d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(kb == 0 ? c.w : c.z, kb == 0 ? s.gap_extend : s.gap_init), yv)));
+                else d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(kb == 0 ? c.y : c.z, kb == 0 ? s.gap_extend : s.gap_init), xv)));
+                if (!valid) d = INFINITY;
+                // first lane with the smallest d, strictly better than what earlier chunks found
+                int win = -1;
+                const unsigned long long zero = __builtin_amdgcn_ballot_w64(valid && d == 0.0f);
+                if (zero != 0ull) {
+                    if (best > 0.0f) { win = __ffsll((long long)zero) - 1; best = 0.0f; }
+                } else {
+                    float m = best;
+                    for (int l = 0; l < 64; ++l) { const float dl = rl_f(d, l); if (m > dl) { m = dl; win = l; } }
+                    best = m;
+                }
+                if (win >= 0) {
+                    found = true;
+                    w_yp = rl_u(yp, win); w_xp = rl_u(xp, win); w_uy = rl_u(uy, win); w_ux = rl_u(ux, win); w_kind = rl_u(kb, win);
+                    w_c = make_float4(rl_f(c.x, win), rl_f(c.y, win), rl_f(c.z, win), rl_f(c.w, win));
+                }
+                if (best == 0.0f) break;   // nothing later in the order can be strictly better
+            }
+            if (!found) { status = PGM_ERR_BACKTRACK; break; }
+            // state of the chosen source (GraphAlign.h:400-411: a W source is resolved by equality in the order M, Y, X)
+            const uint32_t next_y = w_yp, next_x = w_xp;
+            int next_state = current_state;
+            float next_score = INFINITY;
+            bool tr_x = false, tr_y = false;
+            const bool from_w = (current_state == State_m) || w_kind == 1u;
+            if (current_state != State_x) tr_y = w_uy != 0;
+            if (current_state != State_y) tr_x = w_ux != 0;
+            if (!from_w) {
+                next_score = (current_state == State_y) ? w_c.w : w_c.y;      // gap extension: stays in the gap state
+            } else if (next_x != 0 || next_y != 0) {
+                if (w_c.z == w_c.x) { next_score = w_c.x; next_state = State_m; }
+                else if (w_c.z == w_c.w) { next_score = w_c.w; next_state = State_y; }
+                else if (w_c.z == w_c.y) { next_score = w_c.y; next_state = State_x; }
+                else { status = PGM_ERR_BACKTRACK; break; }
+            }
+            n_tr += (uint32_t)tr_x + (uint32_t)tr_y;
+            if (tr_y || tr_x) {
+                if (lane == 0) {
+                    if (tr_y) pgm_mark_alternative_path(J, next_y, y, P1, mo, true);
+                    if (tr_x) pgm_mark_alternative_path(J, next_x, x, P2, mo, false);
+                }
+                mo.len = __builtin_amdgcn_readfirstlane(mo.len);
+            }
+            x = next_x; y = next_y;
+            current_state = next_state;
+            current_score = next_score;
+            if (x != 0 || y != 0) {
+                uint32_t py = y, px = x;
+                if (current_state == State_x) py = 0xFFFFFFFFu;
+                else if (current_state == State_y) px = 0xFFFFFFFFu;
+                if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = py; mo.m2[mo.len] = px; }
+                ++mo.len;
+            }
+        }
+        if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = 0u; mo.m2[mo.len] = 0u; }
+        ++mo.len;
+        if (mo.len > mo.cap) { status = PGM_ERR_BACKTRACK; mo.len = mo.cap; }
+        if (lane == 0) {
+            J.result->score = Wend;
+            J.result->n_tr_indels = n_tr;
+            J.result->len = mo.len;
+            J.result->status = status;
+            T.len = mo.len;
+            T.req = 2;
+        }
+        __syncthreads();                // "request" that ends the loaders' loop
+    }
+    // reverse the two mappings in place (GraphAlign.h:520-521), all threads; thread 0's pushes are ordered by the barrier
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t len = T.len;
+    for (uint32_t i = (uint32_t)tid; i < len / 2; i += (uint32_t)nthreads) {
+        const uint32_t j = len - 1 - i;
+        uint32_t a = J.map1[i], b2 = J.map1[j];
+        J.map1[i] = b2; J.map1[j] = a;
+        a = J.map2[i]; b2 = J.map2[j];
+        J.map2[i] = b2; J.map2[j] = a;
+    }
+}
+
 #define PGM_SPIN_LIMIT (1u << 24)
 
 // ---------------------------------------------------------------------------------------------
@@ -241,25 +588,43 @@ __device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
 // that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
 template <int DUMMY>
-__global__ void __launch_bounds__(256) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
-                                                      int *__restrict__ sync) {
+__global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
+                                                      int *__restrict__ sync, unsigned long long *__restrict__ trace) {
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
     constexpr int NQ = 4;
     constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
     constexpr int PFQ = (BL * NQ + 63) / 64;
-    __shared__ __attribute__((aligned(16))) float4 ring[R * NQ];
-    __shared__ float hW[HW * 64];
-    __shared__ float hY[H * 64];
-    __shared__ float hX[H * 64];
-    __shared__ float2 rep[BL * HR];
-    __shared__ float sblk[2 * BL * 64];
-    __shared__ float res1[2 * 2 * 64];     // [step & 1][M, X][lane]: partial maxima of helper 1 (plain stores)
-    __shared__ float resA[2 * 2 * 64];     // [step & 1][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
-    __shared__ uint32_t el_a[PGM_ENT];     // row-extra entries of the band: distance << 8 | owner lane
-    __shared__ float el_c[PGM_ENT];        //                                 edge cost
-    __shared__ uint32_t ovf[64];           // rows whose entries did not fit (they take the generic path)
-    __shared__ int el_cnt;
-    __shared__ int lds_abort, item_lds;
+    // LDS of the band sweep; the traceback a worker runs after a job's last band reuses the same memory (PgmTbLds)
+    struct FillLds {
+        float4 ring[R * NQ];
+        float hW[HW * 64];
+        float hY[H * 64];
+        float hX[H * 64];
+        float2 rep[BL * HR];
+        float sblk[2 * BL * 64];
+        float res1[2 * 2 * 64];     // [step & 1][M, X][lane]: partial maxima of helper 1 (plain stores)
+        float resA[2 * 2 * 64];     // [step & 1][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
+        uint32_t el_a[PGM_ENT];     // row-extra entries of the band: distance << 8 | owner lane
+        float el_c[PGM_ENT];        //                                 edge cost
+        uint32_t ovf[64];           // rows whose entries did not fit (they take the generic path)
+        int el_cnt;
+        int lds_abort;
+    };
+    __shared__ __attribute__((aligned(16))) union { FillLds f; PgmTbLds t; } L;
+    __shared__ int item_lds, tb_go;
+    float4 (&ring)[R * NQ] = L.f.ring;
+    float (&hW)[HW * 64] = L.f.hW;
+    float (&hY)[H * 64] = L.f.hY;
+    float (&hX)[H * 64] = L.f.hX;
+    float2 (&rep)[BL * HR] = L.f.rep;
+    float (&sblk)[2 * BL * 64] = L.f.sblk;
+    float (&res1)[2 * 2 * 64] = L.f.res1;
+    float (&resA)[2 * 2 * 64] = L.f.resA;
+    uint32_t (&el_a)[PGM_ENT] = L.f.el_a;
+    float (&el_c)[PGM_ENT] = L.f.el_c;
+    uint32_t (&ovf)[64] = L.f.ovf;
+    int &el_cnt = L.f.el_cnt;
+    int &lds_abort = L.f.lds_abort;
 
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
@@ -285,10 +650,14 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel(const PgmJob *__restrict_
         const int it = item_lds;
         if (it < 0) break;
         const PgmItem item = items[it];
+        // optional timeline (tools/probe_trace.py): per item {worker, start, end of band, end of traceback} in 100 MHz ticks
+        if (trace && threadIdx.x == 0) { trace[4 * it] = blockIdx.x; trace[4 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[4 * it + 2] = 0; trace[4 * it + 3] = 0; }
         const PgmJob &J = jobs[item.job];
         const uint32_t b = item.band;
         const bool need_help = J.has_extras != 0;
-        if (role != 0 && !need_help) continue;     // chain-only job: the main wavefront alone (no barriers inside the band)
+        const bool last_band = (b + 1 == J.nb);
+        if (role != 0 && !need_help && !last_band) continue;     // chain-only job: the main wavefront alone (no barriers inside the band)
+        if (role == 0 || need_help) {
         const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
         const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
         const bool comp = lane >= HR;
@@ -735,6 +1104,27 @@ __global__ void __launch_bounds__(256) pgm_fill_kernel(const PgmJob *__restrict_
             __syncthreads();   // band finished: nobody reads the history any more
             if (lds_abort != 0) aborted = true;
         }
+        }   // band body
+        if (trace && threadIdx.x == 0) trace[4 * it + 2] = __builtin_amdgcn_s_memrealtime();
+        if (last_band) {
+            // The last band of a job is the last one to finish, and every cell of the job is written through to memory
+            // by now: this worker walks the traceback (all four wavefronts; helpers of a chain-only job join here).
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const bool ok = !aborted && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; }
+                tb_go = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (tb_go != 0 && !(DUMMY & 8)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
+                pgm_traceback_job(J, L.t, (int)threadIdx.x, 256);
+            }
+            if (trace && threadIdx.x == 0) trace[4 * it + 3] = __builtin_amdgcn_s_memrealtime();
+            // the ring's "column < 0" slots must read as zero again for the next band
+            __syncthreads();
+            if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -753,260 +1143,5 @@ __global__ void __launch_bounds__(256) pgm_emission_kernel(const PgmJob *__restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Traceback (GraphAlign.h:264-521) — one wavefront per job, lane 0 walks END -> START with the
-// reference's tie rules (smallest |current - recomputed|, first candidate in PredIterator order wins,
-// extension tested before opening, state after a W source chosen by equality in the order M, Y, X).
-struct PgmPred {
-    const int32_t *pp; const uint32_t *pc; const float *pv; const uint32_t *pu;
-};
-__device__ __forceinline__ float pgm_mark_value(const PgmPred &P, int32_t e) {
-    // value() with repeat_init = repeat_ext = +inf (markAlternativePath, GraphAlign.h:174)
-    const uint32_t u = P.pu[e];
-    if (u == 0) return P.pv[e];
-    const uint32_t units = u & 0x7fffffffu;
-    if (units == 0) return INFINITY;
-    return __fadd_rn(INFINITY, __fmul_rn(INFINITY, (float)(units - 1)));
-}
-
-struct PgmMapOut {
-    uint32_t *m1, *m2;
-    uint32_t len, cap;
-    __device__ __forceinline__ void push(uint32_t y, uint32_t x) {
-        if (len < cap) { m1[len] = y; m2[len] = x; }
-        ++len;
-    }
-};
-
-__device__ static void pgm_mark_alternative_path(const PgmJob &J, uint32_t start, uint32_t end, const PgmPred &P, PgmMapOut &mo, bool first) {
-    const uint32_t len = end - start + 1;
-    float *score = J.mark_score;
-    uint32_t *prev = J.mark_prev;
-    for (uint32_t i = 0; i < len; ++i) { score[i] = PGM_NEG_INF; prev[i] = 0xFFFFFFFFu; }
-    score[0] = 0.0f;
-    for (uint32_t i = 1; i < len; ++i) {
-        const uint32_t real_ix = i + start;
-        for (int32_t e = P.pp[real_ix]; e < P.pp[real_ix + 1]; ++e) {
-            const uint32_t p = P.pc[e];
-            if (p >= start && p <= end) {
-                const uint32_t i2 = p - start;
-                const float cand = __fsub_rn(score[i2], pgm_mark_value(P, e));
-                if (score[i] <= cand) { score[i] = cand; prev[i] = i2; }
-            }
-        }
-    }
-    if (score[len - 1] > PGM_NEG_INF) {
-        uint32_t i = prev[len - 1];
-        while (i != 0) {
-            if (first) mo.push(i + start, 0xFFFFFFFFu); else mo.push(0xFFFFFFFFu, i + start);
-            i = prev[i];
-        }
-    }
-}
-
-// S(y,x) as the emission kernel stored it (skewed order, see PgmJob::S): one load instead of recomputing the dot product
-__device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, uint32_t x) {
-    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS), t = x + l;
-    return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
-}
-
-// Workgroup = 2 wavefronts: wavefront 0 walks (lane 0), wavefront 1 runs ahead of it and touches the cells of the
-// next PGM_TB_AHEAD anti-diagonals the walk can reach, so that the walker's dependent loads hit L2 instead of HBM
-// (the walk is a pointer chase: one cell decides which cell is read next).
-#define PGM_TB_AHEAD 48
-// (56 VGPRs: the traceback workgroups must fit next to three resident fill workers per CU, 3 x 152 + 56 = 512 per SIMD lane)
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_num_vgpr(56))) pgm_traceback_kernel(const PgmJob *__restrict__ jobs, int *__restrict__ abort_flag) {
-    const PgmJob &J = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
-    __shared__ int s_abort;
-    __shared__ uint32_t s_len;
-    __shared__ int s_pos[2];
-    __shared__ int s_done;
-    if (threadIdx.x == 0) {
-        s_pos[0] = (int)J.n1 - 2; s_pos[1] = (int)J.n2 - 2; s_done = 0;
-        // This kernel runs on a second stream concurrently with the fill kernel: wait until the job's last band is complete
-        // (its cells are written through to memory before the counter is set; nothing of them is cached on this CU yet).
-        uint32_t spins = 0;
-        int ab = 0;
-        while (__hip_atomic_load(&J.prog[J.nb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0x7fffffff) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ab = 1; break; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_abort = ab;
-    }
-    __syncthreads();
-    if (s_abort) {
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE;
-        }
-        return;
-    }
-    if (threadIdx.x >= 64) {
-        // ---- prefetcher wavefront ----
-        const int l = threadIdx.x - 64;
-        int lowest = (int)(J.n1 + J.n2);   // diagonals >= lowest have been touched
-        uint32_t sink = 0;
-        while (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
-            const int y = __hip_atomic_load(&s_pos[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int x = __hip_atomic_load(&s_pos[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int d = y + x;
-            const int target = max(d - PGM_TB_AHEAD, 0);
-            if (lowest > d + 1) lowest = d + 1;
-            if (lowest <= target) { __builtin_amdgcn_s_sleep(8); continue; }
-            for (int dd = lowest - 1; dd >= target; --dd) {
-                // cells (yy, dd - yy) reachable from (y, x): yy <= y, dd - yy <= x
-                const int yy = min(y, dd) - l;
-                const int xx = dd - yy;
-                if (yy >= 0 && xx >= 0 && xx <= x && yy <= (int)J.n1 - 2 && xx <= (int)J.n2 - 2)
-                    sink += __float_as_uint(J.cells[pgm_cell_index(J, (uint32_t)yy, (uint32_t)xx)].x);
-            }
-            lowest = target;
-        }
-        if (sink == 0x7fc12345u) J.mark_prev[0] = sink;   // keeps the loads alive; never true for real scores
-    }
-    if (lane == 0) {
-        const pgm_scores s = J.sc;
-        const uint32_t n1 = J.n1, n2 = J.n2;
-        const PgmPred P1 = {J.pp1, J.pc1, J.pv1, J.pu1};
-        const PgmPred P2 = {J.pp2, J.pc2, J.pv2, J.pu2};
-        int status = PGM_OK;
-        uint32_t n_tr = 0;
-
-        // end node (GraphAlign.h:264-280)
-        float Wend = PGM_NEG_INF;
-        for (int32_t ey = P1.pp[n1 - 1]; ey < P1.pp[n1]; ++ey) {
-            for (int32_t ex = P2.pp[n2 - 1]; ex < P2.pp[n2]; ++ex) {
-                const uint32_t yp = P1.pc[ey], xp = P2.pc[ex];
-                const float yv = P1.pv[ey], xv = P2.pv[ex];
-                if (xp == 0 && yp == 0) {
-                    Wend = fmaxf(__fsub_rn(__fsub_rn(s.end_skip, yv), xv), Wend);
-                } else {
-                    const float4 c = pgm_load_cell(J, yp, xp);
-                    Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv), Wend);
-                    Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv), Wend);
-                    Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv), Wend);
-                }
-            }
-        }
-
-        enum { State_m = 0, State_x = 1, State_y = 2 };
-        int current_state = State_m, next_state = State_m;
-        float current_score = PGM_NEG_INF;
-        uint32_t y = n1 - 1, x = n2 - 1;
-        PgmMapOut mo = {J.map1, J.map2, 0u, n1 + n2};
-        mo.push(n1 - 1, n2 - 1);
-
-        bool tr_x = false, tr_y = false;
-        float best = INFINITY;
-        for (int32_t ey = P1.pp[n1 - 1]; ey < P1.pp[n1]; ++ey) {
-            for (int32_t ex = P2.pp[n2 - 1]; ex < P2.pp[n2]; ++ex) {
-                const uint32_t yp = P1.pc[ey], xp = P2.pc[ex];
-                const float yv = P1.pv[ey], xv = P2.pv[ex];
-                const bool ry = P1.pu[ey] != 0, rx = P2.pu[ex] != 0;
-                const float4 c = pgm_load_cell(J, yp, xp);
-                float d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv)));
-                if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.x; current_state = State_m; y = yp; x = xp; }
-                d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv)));
-                if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.w; current_state = State_y; y = yp; x = xp; }
-                d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv)));
-                if (best > d) { best = d; tr_x = rx; tr_y = ry; current_score = c.y; current_state = State_x; y = yp; x = xp; }
-                d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(s.end_skip, yv), xv)));
-                if (xp == 0 && yp == 0 && best > d) { best = d; tr_x = rx; tr_y = ry; y = yp; x = xp; }
-            }
-        }
-        n_tr += (uint32_t)tr_x + (uint32_t)tr_y;
-        if (tr_y) pgm_mark_alternative_path(J, y, n1 - 1, P1, mo, true);
-        if (tr_x) pgm_mark_alternative_path(J, x, n2 - 1, P2, mo, false);
-        if (x != 0 || y != 0) {
-            if (current_state == State_m) mo.push(y, x);
-            else if (current_state == State_x) mo.push(0xFFFFFFFFu, x);
-            else mo.push(y, 0xFFFFFFFFu);
-        }
-
-        float next_score = INFINITY;
-        uint32_t next_x = 0xFFFFFFFFu, next_y = 0xFFFFFFFFu;
-        uint32_t guard = 0;
-        while ((x != 0 || y != 0) && status == PGM_OK) {
-            if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
-            __hip_atomic_store(&s_pos[0], (int)y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&s_pos[1], (int)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            best = INFINITY;
-            // choose the state of a W source by equality, order M, Y, X (GraphAlign.h:400-411)
-#define PGM_PICK(cell)                                                                        \
-    if (next_x != 0 || next_y != 0) {                                                          \
-        if ((cell).z == (cell).x) { next_score = (cell).x; next_state = State_m; }              \
-        else if ((cell).z == (cell).w) { next_score = (cell).w; next_state = State_y; }         \
-        else if ((cell).z == (cell).y) { next_score = (cell).y; next_state = State_x; }         \
-        else status = PGM_ERR_BACKTRACK;                                                       \
-    }
-            if (current_state == State_y) {
-                for (int32_t e = P1.pp[y]; e < P1.pp[y + 1]; ++e) {
-                    const uint32_t yp = P1.pc[e];
-                    const float yv = P1.pv[e];
-                    const float4 c = pgm_load_cell(J, yp, x);
-                    float d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(c.w, s.gap_extend), yv)));
-                    if (best > d) { best = d; tr_x = false; tr_y = P1.pu[e] != 0; next_x = x; next_y = yp; next_score = c.w; next_state = State_y; }
-                    d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(c.z, s.gap_init), yv)));
-                    if (best > d) { best = d; tr_x = false; tr_y = P1.pu[e] != 0; next_x = x; next_y = yp; PGM_PICK(c) }
-                }
-            } else if (current_state == State_x) {
-                for (int32_t e = P2.pp[x]; e < P2.pp[x + 1]; ++e) {
-                    const uint32_t xp = P2.pc[e];
-                    const float xv = P2.pv[e];
-                    const float4 c = pgm_load_cell(J, y, xp);
-                    float d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(c.y, s.gap_extend), xv)));
-                    if (best > d) { best = d; tr_x = P2.pu[e] != 0; tr_y = false; next_x = xp; next_y = y; next_score = c.y; next_state = State_x; }
-                    d = fabsf(__fsub_rn(current_score, __fsub_rn(__fadd_rn(c.z, s.gap_init), xv)));
-                    if (best > d) { best = d; tr_x = P2.pu[e] != 0; tr_y = false; next_x = xp; next_y = y; PGM_PICK(c) }
-                }
-            } else {
-                const float S = pgm_emission_at(J, y, x);
-                for (int32_t ey = P1.pp[y]; ey < P1.pp[y + 1]; ++ey) {
-                    for (int32_t ex = P2.pp[x]; ex < P2.pp[x + 1]; ++ex) {
-                        const uint32_t yp = P1.pc[ey], xp = P2.pc[ex];
-                        const float yv = P1.pv[ey], xv = P2.pv[ex];
-                        const float4 c = pgm_load_cell(J, yp, xp);
-                        const float d = fabsf(__fsub_rn(current_score, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
-                        if (best > d) { best = d; tr_x = P2.pu[ex] != 0; tr_y = P1.pu[ey] != 0; next_y = yp; next_x = xp; PGM_PICK(c) }
-                    }
-                }
-            }
-#undef PGM_PICK
-            if (status != PGM_OK) break;
-            n_tr += (uint32_t)tr_x + (uint32_t)tr_y;
-            if (tr_y) pgm_mark_alternative_path(J, next_y, y, P1, mo, true);
-            if (tr_x) pgm_mark_alternative_path(J, next_x, x, P2, mo, false);
-            x = next_x; y = next_y;
-            current_state = next_state;
-            current_score = next_score;
-            if (x != 0 || y != 0) {
-                if (current_state == State_m) mo.push(y, x);
-                else if (current_state == State_x) mo.push(0xFFFFFFFFu, x);
-                else mo.push(y, 0xFFFFFFFFu);
-            }
-        }
-        mo.push(0, 0);
-        if (mo.len > mo.cap) { status = PGM_ERR_BACKTRACK; mo.len = mo.cap; }
-        J.result->score = Wend;
-        J.result->n_tr_indels = n_tr;
-        J.result->len = mo.len;
-        J.result->status = status;
-        s_len = mo.len;
-        __hip_atomic_store(&s_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __syncthreads();
-    // reverse the two mappings in place (GraphAlign.h:520-521), all 128 threads
-    const uint32_t len = s_len;
-    __threadfence_block();
-    for (uint32_t i = lane; i < len / 2; i += 128) {
-        const uint32_t j = len - 1 - i;
-        uint32_t a = J.map1[i], b2 = J.map1[j];
-        J.map1[i] = b2; J.map1[j] = a;
-        a = J.map2[i]; b2 = J.map2[j];
-        J.map2[i] = b2; J.map2[j] = a;
-    }
-}
 
 #endif

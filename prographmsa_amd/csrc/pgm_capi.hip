@@ -29,8 +29,6 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 struct pgm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // traceback runs here, concurrently with the fill kernel
-    hipEvent_t ev_ready = nullptr, ev_tb = nullptr;
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0;
     // context-profile library resident in HBM
@@ -73,6 +71,7 @@ struct pgm_align_batch {
     int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
     size_t sync_ints = 0, s_bytes = 0;
     PgmItem *d_items = nullptr;       // band list of the batch (fill work queue)
+    unsigned long long *d_trace = nullptr;   // PGM_FILL_TRACE=file: per-item timeline, written by fetch (tools only)
     uint32_t nitems = 0;
     uint32_t nworkers = 0, maxnblk = 0;
     PgmJob *d_jobs = nullptr;
@@ -103,9 +102,6 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     c->device = device;
     HIPCHK(hipGetDeviceProperties(&c->prop, device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_tb, hipEventDisableTiming));
     *out = c;
     return PGM_OK;
 }
@@ -117,9 +113,6 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
-    if (ctx->ev_tb) (void)hipEventDestroy(ctx->ev_tb);
     delete ctx;
 }
 
@@ -224,20 +217,13 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
-    // The traceback workgroups are launched on a second stream and start as soon as their job's last band is published,
-    // so the walks of all small jobs overlap the fill of the large ones.
-    if ((e = hipEventRecord(ctx->ev_ready, s)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(ctx->stream2, ctx->ev_ready, 0)) != hipSuccess) return e;
+    // One kernel does the DP fill of every band and, right after a job's last band, that job's traceback.
     const char *dbg = getenv("PGM_FILL_DBG");   // 8: cycle-counter build of the fill kernel (tools/probe_cyc.py), no traceback
     const int dbgv = dbg ? atoi(dbg) : 0;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync);
-    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (dbgv == 0) hipLaunchKernelGGL(pgm_traceback_kernel, dim3(b->njobs), dim3(128), 0, ctx->stream2, b->d_jobs, b->d_sync);
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
+    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
-    if ((e = hipEventRecord(ctx->ev_tb, ctx->stream2)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, ctx->ev_tb, 0)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -356,8 +342,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         const double lag = PGM_ROWS + 4.0 * PGM_BLOCK;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
-            const double tau = J.has_extras ? 0.65 : 0.38;
-            for (uint32_t band = 0; band < J.nb; ++band) keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps), i, band});
+            const double tau = J.has_extras ? 0.65 : 0.38;      // us per step
+            const double tb = 0.35 * (double)(J.n1 + J.n2);      // the traceback follows the last band (us)
+            for (uint32_t band = 0; band < J.nb; ++band) keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb, i, band});
         }
         std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.rem > y.rem; });
         items.reserve(keys.size());
@@ -370,6 +357,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }
+    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 32 * items.size());
     if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -428,7 +416,17 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     HIPCHK(hipMemcpyAsync(b->h_out.data(), b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&aborted, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out (workers not co-resident?)");
+    if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
+    if (b->d_trace) {
+        // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
+        std::vector<unsigned long long> tr(4 * (size_t)b->nitems);
+        std::vector<PgmItem> its(b->nitems);
+        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 32 * (size_t)b->nitems, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(its.data(), b->d_items, sizeof(PgmItem) * b->nitems, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("PGM_FILL_TRACE") ? getenv("PGM_FILL_TRACE") : "/dev/null", "wb")) {
+            fwrite(&b->nitems, 4, 1, f); fwrite(its.data(), sizeof(PgmItem), b->nitems, f); fwrite(tr.data(), 8, tr.size(), f); fclose(f);
+        }
+    }
     for (uint32_t i = 0; i < b->njobs; ++i) {
         PgmJob::Result res;
         memcpy(&res, b->h_out.data() + b->res_off[i], sizeof res);
@@ -458,6 +456,7 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (b->d_S) (void)hipFree(b->d_S);
     if (b->d_sync) (void)hipFree(b->d_sync);
     if (b->d_items) (void)hipFree(b->d_items);
+    if (b->d_trace) (void)hipFree(b->d_trace);
     if (b->d_jobs) (void)hipFree(b->d_jobs);
     if (b->d_order) (void)hipFree(b->d_order);
     delete b;

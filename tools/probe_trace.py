@@ -1,0 +1,41 @@
+"""Timeline of the fill kernel's band queue on the headline batch (GPU box): PGM_FILL_TRACE dump -> utilisation summary."""
+import os, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gen
+tmp = tempfile.mkdtemp()
+trace = os.path.join(tmp, "trace.bin")
+import prographmsa_amd as pg
+from prographmsa_amd import jobs as J
+fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(gen.gen(256, 1000, 3)))
+dump = os.path.join(tmp, "jobs.bin")
+subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree"), "--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
+jobs = J.load_jobs(dump)
+os.environ["PGM_FILL_TRACE"] = trace
+ctx = pg.Context(0)
+b = J.Batch(ctx, jobs)
+b.run(); b.fetch(); b.run(); b.fetch()
+buf = open(trace, "rb").read()
+n = np.frombuffer(buf, np.uint32, 1)[0]
+items = np.frombuffer(buf, np.uint32, 2 * n, 4).reshape(n, 2)
+tr = np.frombuffer(buf, np.uint64, 4 * n, 4 + 8 * n).reshape(n, 4).astype(np.float64)
+t0 = tr[:, 1].min()
+start, bend, tend = (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0, np.where(tr[:, 3] > 0, (tr[:, 3] - t0) / 100.0, 0)   # us
+end = np.maximum(bend, tend)
+print("items %d, workers %d, makespan %.0f us" % (n, len(set(tr[:, 0])), end.max()))
+busy = (end - start).sum()
+print("sum of item times %.0f us-worker = %.1f%% of workers x makespan" % (busy, 100 * busy / (len(set(tr[:, 0])) * end.max())))
+tb = np.where(tend > 0, tend - bend, 0)
+print("traceback: %d items, total %.0f us-worker, max %.0f us" % ((tend > 0).sum(), tb.sum(), tb.max()))
+sizes = np.array([(j.g1.n, j.g2.n) for j in jobs])
+for q in (0.5, 0.75, 0.9, 0.95, 0.99, 1.0):
+    print("  %3.0f%% of items started by %.0f us, ended by %.0f us" % (100 * q, np.quantile(start, q), np.quantile(end, q)))
+late = np.argsort(-end)[:12]
+for i in late:
+    j, bd = items[i]
+    print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 47) // 48, start[i], bend[i], tend[i]))
+# per-job: first start, last end
+for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
+    m = items[:, 0] == sel
+    print("root job: bands %d, first start %.0f, last band end %.0f, tb end %.0f" % (m.sum(), start[m].min(), bend[m].max(), tend[m].max()))
