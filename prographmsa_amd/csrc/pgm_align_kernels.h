@@ -43,44 +43,49 @@ __device__ __forceinline__ float pgm_emission_finish(float num, float ay, float 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Prep kernel: float casts, T = M^T g2, per-node denominators.  grid = (njobs, 2), block = 256.
+// Prep kernel: float casts, T = M^T g2, per-node denominators.  grid = (njobs, 2, slices), block = 256; the nodes of a
+// graph are dealt to the slices (one thread per node), so the largest job's graphs do not serialise on one workgroup.
 //   side 0: g1f[y][k] = float(sites1(k,y));  a1[y] = sum_k g1f[y][k] * pi_f[k]
 //   side 1: t2[x][k]  = sum_j M_f(j,k) * g2f(j,x);  b2[x] = sum_k pi_f[k] g2f(k,x)
+// A node's profile column is read into registers once (DMAX = 20 for amino acids, 64 for codons); the sums keep the
+// reference's sequential order (one multiply and one add per term, no FMA).
+template <int DMAX>
 __global__ void __launch_bounds__(256) pgm_prep_kernel(const PgmJob *__restrict__ jobs) {
     extern __shared__ float prep_lds[];  // Mf (dim*dim) then pif (dim)
     const PgmJob &J = jobs[blockIdx.x];
+    if (blockIdx.z * blockDim.x >= (blockIdx.y == 0 ? J.n1 : J.n2)) return;   // no nodes for this slice
     const uint32_t D = J.dim, DP = J.dp;
     float *Mf = prep_lds;
     float *pif = prep_lds + D * D;
     for (uint32_t i = threadIdx.x; i < D * D; i += blockDim.x) Mf[i] = (float)J.M[i];
     for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) pif[i] = (float)J.pi[i];
     __syncthreads();
-    if (blockIdx.y == 0) {
-        for (uint32_t y = threadIdx.x; y < J.n1; y += blockDim.x) {
-            const double *col = J.sites1 + (size_t)D * y;
-            float *dst = J.g1f + (size_t)DP * y;
-            float acc = 0.0f;
+    const bool first = blockIdx.y == 0;
+    const uint32_t n = first ? J.n1 : J.n2;
+    for (uint32_t v = blockIdx.z * blockDim.x + threadIdx.x; v < n; v += blockDim.x * gridDim.z) {
+        const double *col = (first ? J.sites1 : J.sites2) + (size_t)D * v;
+        float g[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) g[k] = ((uint32_t)k < D) ? (float)col[k] : 0.0f;
+        float *dst = (first ? J.g1f : J.t2) + (size_t)DP * v;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k)
+            if ((uint32_t)k < D) acc = __fadd_rn(acc, __fmul_rn(first ? g[k] : pif[k], first ? pif[k] : g[k]));
+        if (first) {
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) if ((uint32_t)k < DP) dst[k] = g[k];
+            J.a1[v] = acc;
+        } else {
             for (uint32_t k = 0; k < D; ++k) {
-                const float g = (float)col[k];
-                dst[k] = g;
-                acc = __fadd_rn(acc, __fmul_rn(g, pif[k]));
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < DMAX; ++j)
+                    if ((uint32_t)j < D) t = __fadd_rn(t, __fmul_rn(Mf[j + D * k], g[j]));
+                dst[k] = t;
             }
             for (uint32_t k = D; k < DP; ++k) dst[k] = 0.0f;
-            J.a1[y] = acc;
-        }
-    } else {
-        for (uint32_t x = threadIdx.x; x < J.n2; x += blockDim.x) {
-            const double *col = J.sites2 + (size_t)D * x;
-            float *dst = J.t2 + (size_t)DP * x;
-            for (uint32_t k = 0; k < D; ++k) {
-                float acc = 0.0f;
-                for (uint32_t j = 0; j < D; ++j) acc = __fadd_rn(acc, __fmul_rn(Mf[j + D * k], (float)col[j]));
-                dst[k] = acc;
-            }
-            for (uint32_t k = D; k < DP; ++k) dst[k] = 0.0f;
-            float b = 0.0f;
-            for (uint32_t k = 0; k < D; ++k) b = __fadd_rn(b, __fmul_rn(pif[k], (float)col[k]));
-            J.b2[x] = b;
+            J.b2[v] = acc;
         }
     }
 }
@@ -214,7 +219,7 @@ __device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y
 // W source chosen by equality in the order M, Y, X).  The walk is a pointer chase (one cell decides which cell is
 // read next), so the whole workgroup stages a 32 x 32 TILE of cells, emission scores and predecessor lists around the
 // walker's position in LDS; the walker then reads LDS (~100 cycles) instead of L2/HBM (~1000 cycles) per dependent
-// access and asks for a new tile when it gets within PGM_TB_MARGIN rows or columns of the tile's low edge.  Anything
+// access and asks for a new tile when it gets within a few rows or columns of the tile's low edge.  Anything
 // outside the tile (far skip / repeat edges, nodes with more than 8 predecessors) is read from memory as before.
 struct PgmPred {
     const int32_t *pp; const uint32_t *pc; const float *pv; const uint32_t *pu;
@@ -270,7 +275,7 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 }
 
 #define PGM_TB_T 32        // tile edge (rows and columns)
-#define PGM_TB_MARGIN 8    // a new tile is staged when the walker is closer than this to the tile's low edge
+#define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's
 #define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
 struct PgmTbLds {
     float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
@@ -279,7 +284,9 @@ struct PgmTbLds {
     uint32_t p_c[2 * PGM_TB_T * PGM_TB_PK];    // predecessor node, PredIterator order
     float p_v[2 * PGM_TB_T * PGM_TB_PK];       // edge value
     uint32_t p_u[2 * PGM_TB_T * PGM_TB_PK];    // repeat marker
+    uint16_t succ[3 * PGM_TB_T * PGM_TB_T];    // [state][cell]: precomputed successor (see pgm_tb_succ), 0 = not available
     uint32_t ty0, tx0;                         // tile origin
+    uint32_t ay, ax;                           // walker position the tile was requested for (centre of the link band)
     int req;                                   // 1: stage a tile at (ty0, tx0); 2: walk finished
     uint32_t len;
 };
@@ -291,47 +298,167 @@ struct PgmPredView {
     uint32_t base;     // LDS: slot * PGM_TB_PK; memory: first entry index
 };
 
-__device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads) {
+__device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads, unsigned long long *stat) {
     constexpr uint32_t TT = PGM_TB_T;
     const uint32_t n1 = J.n1, n2 = J.n2;
     const PgmPred P1 = {J.pp1, J.pc1, J.pv1, J.pu1};
     const PgmPred P2 = {J.pp2, J.pc2, J.pv2, J.pu2};
 
-    // ---- tile staging: wavefronts 1.. (a barrier is per wavefront, so the walker's wavefront 0 cannot also be a loader:
-    // its lanes 1..63 simply sit out the walk) ----------------------------------------------------------------------
-    const bool loader = tid >= 64;
-    const uint32_t ltid = (uint32_t)(tid - 64), nload = (uint32_t)(nthreads - 64);
+    // ---- tile staging, all threads (nthreads == 256: 4 cells and 2 predecessor entries each).  All loads of a thread
+    // are issued before the first LDS store (clamped, always valid addresses instead of branches), so a tile costs two
+    // memory round trips (row pointers -> entries), not one per element. -------------------------------------------
+    const bool loader = tid >= 64;   // wavefronts 1..: they only serve the walker (wavefront 0)
     auto stage = [&]() {
         const uint32_t ty0 = T.ty0, tx0 = T.tx0;
-        for (uint32_t i = ltid; i < TT * TT; i += nload) {
-            const uint32_t yy = ty0 + i / TT, xx = tx0 + i % TT;
-            if (yy + 1 < n1 && xx + 1 < n2) {
-                T.cell[i] = J.cells[pgm_cell_index(J, yy, xx)];
-                T.S[i] = pgm_emission_at(J, yy, xx);
-            }
+        constexpr int NC = (int)(TT * TT) / 256, NP = (int)(2 * TT * PGM_TB_PK) / 256;
+        float4 cv[NC];
+        float sv[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u;
+            const uint32_t yy = min(ty0 + i / TT, n1 - 2), xx = min(tx0 + i % TT, n2 - 2);
+            cv[u] = J.cells[pgm_cell_index(J, yy, xx)];
+            sv[u] = pgm_emission_at(J, yy, xx);
         }
-        for (uint32_t i = ltid; i < 2 * TT * PGM_TB_PK; i += nload) {
-            const uint32_t slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+        int32_t eb[NP];
+        uint32_t cnt[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK;
             const bool row = slot < TT;
-            const uint32_t v = row ? ty0 + slot : tx0 + (slot - TT);
+            const uint32_t v = min(row ? ty0 + slot : tx0 + (slot - TT), (row ? n1 : n2) - 1);
             const PgmPred &P = row ? P1 : P2;
-            if (v < (row ? n1 : n2)) {
-                const int32_t eb = P.pp[v], ee = P.pp[v + 1];
-                const uint32_t cnt = (uint32_t)(ee - eb);
-                if (k == 0) T.p_cnt[slot] = cnt;
-                if (k < cnt && cnt <= PGM_TB_PK) { T.p_c[i] = P.pc[eb + k]; T.p_v[i] = P.pv[eb + k]; T.p_u[i] = P.pu[eb + k]; }
-            } else if (k == 0) {
-                T.p_cnt[slot] = 0xFFFFFFFFu;
+            eb[u] = P.pp[v];
+            cnt[u] = (uint32_t)(P.pp[v + 1] - eb[u]);
+        }
+        uint32_t ec[NP], eu[NP];
+        float ev[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const PgmPred &P = slot < TT ? P1 : P2;
+            const int32_t e = cnt[u] == 0u ? 0 : eb[u] + (int32_t)min(k, cnt[u] - 1u);
+            ec[u] = P.pc[e]; ev[u] = P.pv[e]; eu[u] = P.pu[e];
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u;
+            T.cell[i] = cv[u];
+            T.S[i] = sv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const bool row = slot < TT;
+            const bool inr = (row ? ty0 + slot : tx0 + (slot - TT)) < (row ? n1 : n2);
+            if (k == 0) T.p_cnt[slot] = inr ? cnt[u] : 0xFFFFFFFFu;
+            T.p_c[i] = ec[u]; T.p_v[i] = ev[u]; T.p_u[i] = eu[u];
+        }
+    };
+    // ---- successor table, all threads: for every cell of the tile and each of the three states the walk's next
+    // (cell, state), decided exactly as the walker would (same candidates, same order, same strict comparisons).  The
+    // walker then follows 16-bit links (one LDS read per step) and only evaluates candidates itself where no link
+    // exists: predecessors outside the tile, more than PGM_TB_PK predecessors, tandem-repeat edges, inconsistencies.
+    // Link: bit 15 valid, bits 10..11 next state (0 M, 1 X, 2 Y), bits 5..9 / 0..4 next row / column inside the tile.
+    const pgm_scores sc = J.sc;
+    // Only for the cells within PGM_TB_BAND diagonals of the walker's position (T.ay, T.ax) when the tile was requested:
+    // an alignment path mostly runs along that diagonal; off the band the walker asks for a new tile.
+    auto links = [&]() {
+        const uint32_t ty0 = T.ty0, tx0 = T.tx0;
+        const int adiag = (int)(T.ay - ty0) - (int)(T.ax - tx0);
+        for (uint32_t ci = (uint32_t)tid; ci < TT * TT; ci += (uint32_t)nthreads) {
+            const uint32_t ly = ci / TT, lx = ci % TT, y = ty0 + ly, x = tx0 + lx;
+            uint16_t lm = 0, lxs = 0, lys = 0;
+            const int off = (int)ly - (int)lx - adiag;
+            if (y + 1 < n1 && x + 1 < n2 && (y | x) != 0u && off >= -PGM_TB_BAND && off <= PGM_TB_BAND) {
+                const float4 c0 = T.cell[ci];
+                const uint32_t cy = T.p_cnt[ly], cx = T.p_cnt[TT + lx];
+                const bool oky = cy <= PGM_TB_PK, okx = cx <= PGM_TB_PK;
+                auto pick = [&](const float4 &c, uint32_t yp, uint32_t xp) -> uint16_t {   // W source resolved by equality: M, Y, X
+                    uint32_t st;
+                    if ((yp | xp) == 0u) st = 0u;
+                    else if (c.z == c.x) st = 0u;
+                    else if (c.z == c.w) st = 2u;
+                    else if (c.z == c.y) st = 1u;
+                    else return (uint16_t)0;
+                    return (uint16_t)(0x8000u | (st << 10) | ((yp - ty0) << 5) | (xp - tx0));
+                };
+                // state M: pairs (row predecessor outer, column predecessor inner)
+                if (oky && okx && c0.x > PGM_NEG_INF) {
+                    const float S = T.S[ci];
+                    float best = INFINITY;
+                    bool ok = true, rep_edge = false;
+                    uint32_t wy = 0, wx = 0;
+                    float4 wc = c0;
+                    for (uint32_t ky = 0; ky < cy && ok; ++ky) {
+                        const uint32_t yp = T.p_c[ly * PGM_TB_PK + ky];
+                        const float yv = T.p_v[ly * PGM_TB_PK + ky];
+                        if (yp < ty0) { ok = false; break; }
+                        for (uint32_t kx = 0; kx < cx; ++kx) {
+                            const uint32_t xp = T.p_c[(TT + lx) * PGM_TB_PK + kx];
+                            if (xp < tx0) { ok = false; break; }
+                            const float xv = T.p_v[(TT + lx) * PGM_TB_PK + kx];
+                            const float4 c = T.cell[(yp - ty0) * TT + (xp - tx0)];
+                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
+                            if (best > d) { best = d; wy = yp; wx = xp; wc = c; rep_edge = (T.p_u[ly * PGM_TB_PK + ky] | T.p_u[(TT + lx) * PGM_TB_PK + kx]) != 0u; }
+                        }
+                    }
+                    if (ok && best < INFINITY && !rep_edge) lm = pick(wc, wy, wx);
+                }
+                // state Y: row predecessors, extension before opening
+                if (oky && c0.w > PGM_NEG_INF) {
+                    float best = INFINITY;
+                    bool ok = true, rep_edge = false, open = false;
+                    uint32_t wy = 0;
+                    float4 wc = c0;
+                    for (uint32_t k = 0; k < cy; ++k) {
+                        const uint32_t yp = T.p_c[ly * PGM_TB_PK + k];
+                        if (yp < ty0) { ok = false; break; }
+                        const float yv = T.p_v[ly * PGM_TB_PK + k];
+                        const float4 c = T.cell[(yp - ty0) * TT + lx];
+                        const bool ru = T.p_u[ly * PGM_TB_PK + k] != 0u;
+                        float d = fabsf(__fsub_rn(c0.w, __fsub_rn(__fadd_rn(c.w, sc.gap_extend), yv)));
+                        if (best > d) { best = d; wy = yp; wc = c; rep_edge = ru; open = false; }
+                        d = fabsf(__fsub_rn(c0.w, __fsub_rn(__fadd_rn(c.z, sc.gap_init), yv)));
+                        if (best > d) { best = d; wy = yp; wc = c; rep_edge = ru; open = true; }
+                    }
+                    if (ok && best < INFINITY && !rep_edge)
+                        lys = open ? pick(wc, wy, x) : (uint16_t)(0x8000u | (2u << 10) | ((wy - ty0) << 5) | lx);
+                }
+                // state X: column predecessors
+                if (okx && c0.y > PGM_NEG_INF) {
+                    float best = INFINITY;
+                    bool ok = true, rep_edge = false, open = false;
+                    uint32_t wx = 0;
+                    float4 wc = c0;
+                    for (uint32_t k = 0; k < cx; ++k) {
+                        const uint32_t xp = T.p_c[(TT + lx) * PGM_TB_PK + k];
+                        if (xp < tx0) { ok = false; break; }
+                        const float xv = T.p_v[(TT + lx) * PGM_TB_PK + k];
+                        const float4 c = T.cell[ly * TT + (xp - tx0)];
+                        const bool ru = T.p_u[(TT + lx) * PGM_TB_PK + k] != 0u;
+                        float d = fabsf(__fsub_rn(c0.y, __fsub_rn(__fadd_rn(c.y, sc.gap_extend), xv)));
+                        if (best > d) { best = d; wx = xp; wc = c; rep_edge = ru; open = false; }
+                        d = fabsf(__fsub_rn(c0.y, __fsub_rn(__fadd_rn(c.z, sc.gap_init), xv)));
+                        if (best > d) { best = d; wx = xp; wc = c; rep_edge = ru; open = true; }
+                    }
+                    if (ok && best < INFINITY && !rep_edge)
+                        lxs = open ? pick(wc, y, wx) : (uint16_t)(0x8000u | (1u << 10) | (ly << 5) | (wx - tx0));
+                }
             }
+            T.succ[ci] = lm; T.succ[TT * TT + ci] = lxs; T.succ[2 * TT * TT + ci] = lys;
         }
     };
     if (tid == 0) {
         T.ty0 = n1 - 2 >= TT - 1 ? n1 - 2 - (TT - 1) : 0u;
         T.tx0 = n2 - 2 >= TT - 1 ? n2 - 2 - (TT - 1) : 0u;
+        T.ay = n1 - 2; T.ax = n2 - 2;
         T.req = 1;
     }
     __syncthreads();
-    if (loader) stage();
+    stage();
+    __syncthreads();
+    links();
     __syncthreads();
 
     if (loader) {
@@ -340,13 +467,16 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             __syncthreads();            // request posted
             if (T.req == 2) break;
             stage();
-            __syncthreads();            // tile staged
+            __syncthreads();            // cells, scores, predecessor lists staged
+            links();
+            __syncthreads();            // successor table complete
         }
     } else {
         // ---- walker: wavefront 0, uniform control flow; the one-off END step is evaluated by lane 0 alone ----
         const int lane = tid;
         const pgm_scores s = J.sc;
-        uint32_t ty0 = T.ty0, tx0 = T.tx0;
+        uint32_t ty0 = T.ty0, tx0 = T.tx0, ay = T.ay, ax = T.ax;
+        int adiag = (int)(ay - ty0) - (int)(ax - tx0);
         auto in_tile = [&](uint32_t y, uint32_t x) { return (y - ty0) < TT && (x - tx0) < TT; };
         auto cell_at = [&](uint32_t y, uint32_t x) -> float4 {
             if (in_tile(y, x)) return T.cell[(y - ty0) * TT + (x - tx0)];
@@ -437,16 +567,56 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         // one ballot finds; only if no lane is exact the minimum is searched lane by lane.
         auto rl_u = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
         auto rl_f = [](float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+        // a new tile is staged when the walker is closer than `margin` to the tile's low edge: predecessors of chain-only
+        // graphs are 1 node back; in merged graphs most skip edges span a few nodes (farther ones are read from memory)
+        const uint32_t margin = J.has_extras ? 4u : 1u;
         uint32_t guard = 0;
+        unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0;
+        bool score_stale = false;
         while ((x != 0 || y != 0) && status == PGM_OK) {
             if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
+            // the walker state is the same in all lanes: keep it in scalar registers so that the branches below are scalar
+            y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x);
+            current_state = __builtin_amdgcn_readfirstlane(current_state);
             // new tile when the walker is near the low edge of the current one (or outside it, after a far edge)
-            if (((y - ty0) >= TT || ((y - ty0) < PGM_TB_MARGIN && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < PGM_TB_MARGIN && tx0 != 0))) {
+            const int offb = ((int)(y - ty0) - (int)(x - tx0)) - adiag;
+            if (((y - ty0) >= TT || ((y - ty0) < margin && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < margin && tx0 != 0)) ||
+                ((offb < -PGM_TB_BAND || offb > PGM_TB_BAND) && (y != ay || x != ax))) {
                 ty0 = y >= TT - 1 ? y - (TT - 1) : 0u;
                 tx0 = x >= TT - 1 ? x - (TT - 1) : 0u;
-                if (lane == 0) { T.ty0 = ty0; T.tx0 = tx0; T.req = 1; }
+                const unsigned long long r0 = stat ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                ay = y; ax = x; adiag = (int)(y - ty0) - (int)(x - tx0);
+                if (lane == 0) { T.ty0 = ty0; T.tx0 = tx0; T.ay = y; T.ax = x; T.req = 1; }
                 __syncthreads();        // request posted
-                __syncthreads();        // tile staged
+                stage();
+                __syncthreads();        // cells, scores, predecessor lists staged
+                links();
+                __syncthreads();        // successor table complete
+                if (stat) { st_reload += __builtin_amdgcn_s_memrealtime() - r0; ++st_nreload; }
+            }
+            // fast path: follow the precomputed link of (cell, state)
+            if (in_tile(y, x)) {
+                const uint32_t code = T.succ[(uint32_t)(current_state == State_m ? 0 : (current_state == State_x ? 1 : 2)) * (TT * TT) + (y - ty0) * TT + (x - tx0)];
+                if (code & 0x8000u) {
+                    y = ty0 + ((code >> 5) & 31u); x = tx0 + (code & 31u);
+                    const uint32_t st = (code >> 10) & 3u;
+                    current_state = st == 0u ? State_m : (st == 1u ? State_x : State_y);
+                    score_stale = true;
+                    if (x != 0 || y != 0) {
+                        uint32_t py = y, px = x;
+                        if (current_state == State_x) py = 0xFFFFFFFFu;
+                        else if (current_state == State_y) px = 0xFFFFFFFFu;
+                        if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = py; mo.m2[mo.len] = px; }
+                        ++mo.len;
+                    }
+                    continue;
+                }
+            }
+            ++st_slow;
+            if (score_stale) {   // the score of (cell, state) is the cell's value for that state
+                const float4 c = cell_at(y, x);
+                current_score = current_state == State_m ? c.x : (current_state == State_x ? c.y : c.w);
+                score_stale = false;
             }
             const bool need_y = current_state != State_x, need_x = current_state != State_y;
             PgmPredView Vy = {1u, false, 0u}, Vx = {1u, false, 0u};
@@ -455,15 +625,20 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             const float S = (current_state == State_m) ? s_at(y, x) : 0.0f;
             // candidates: state M: (ky, kx) pairs; state Y / X: (k, extend | open)
             const uint32_t per = (current_state == State_m) ? Vx.cnt : 2u;
-            const uint32_t total = (current_state == State_m) ? Vy.cnt * Vx.cnt : 2u * (need_y ? Vy.cnt : Vx.cnt);
+            // state M with at most 8 x 8 pairs: lane = ky * 8 + kx (one chunk, lane order = PredIterator order, no division)
+            const bool small = Vy.cnt <= 8u && Vx.cnt <= 8u;
+            const uint32_t total = (current_state == State_m) ? (small ? (Vy.cnt && Vx.cnt ? 64u : 0u) : Vy.cnt * Vx.cnt) : 2u * (need_y ? Vy.cnt : Vx.cnt);
             float best = INFINITY;
             uint32_t w_yp = 0xFFFFFFFFu, w_xp = 0xFFFFFFFFu, w_uy = 0, w_ux = 0, w_kind = 0;
             float4 w_c = make_float4(0.f, 0.f, 0.f, 0.f);
             bool found = false;
             for (uint32_t base = 0; base < total; base += 64u) {
                 const uint32_t i = base + (uint32_t)lane;
-                const bool valid = i < total;
-                const uint32_t ka = valid ? i / per : 0u, kb = valid ? i % per : 0u;   // (ky, kx) or (k, kind)
+                const bool valid = (current_state == State_m && small) ? (((uint32_t)lane >> 3) < Vy.cnt && ((uint32_t)lane & 7u) < Vx.cnt) : i < total;
+                uint32_t ka, kb;   // (ky, kx) or (k, kind)
+                if (current_state != State_m) { ka = i >> 1; kb = i & 1u; }
+                else if (small) { ka = (uint32_t)lane >> 3; kb = (uint32_t)lane & 7u; }
+                else { ka = valid ? i / per : 0u; kb = valid ? i % per : 0u; }
                 uint32_t yp = y, xp = x, uy = 0, ux = 0;
                 float yv = 0.0f, xv = 0.0f;
                 if (need_y) { const uint32_t k = ka; if (valid) { yp = pc_of(true, Vy, k); yv = pv_of(true, Vy, k); uy = pu_of(true, Vy, k); } }
@@ -538,6 +713,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             J.result->status = status;
             T.len = mo.len;
             T.req = 2;
+            if (stat) { stat[0] = st_reload; stat[1] = (st_nreload << 32) | st_slow; }
         }
         __syncthreads();                // "request" that ends the loaders' loop
     }
@@ -650,8 +826,12 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
         const int it = item_lds;
         if (it < 0) break;
         const PgmItem item = items[it];
+        {   // s_setprio takes an immediate
+            const uint32_t pr = __builtin_amdgcn_readfirstlane(item.prio);
+            if (pr >= 3u) __builtin_amdgcn_s_setprio(3); else if (pr == 2u) __builtin_amdgcn_s_setprio(2); else if (pr == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         // optional timeline (tools/probe_trace.py): per item {worker, start, end of band, end of traceback} in 100 MHz ticks
-        if (trace && threadIdx.x == 0) { trace[4 * it] = blockIdx.x; trace[4 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[4 * it + 2] = 0; trace[4 * it + 3] = 0; }
+        if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
         const PgmJob &J = jobs[item.job];
         const uint32_t b = item.band;
         const bool need_help = J.has_extras != 0;
@@ -1105,7 +1285,7 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
             if (lds_abort != 0) aborted = true;
         }
         }   // band body
-        if (trace && threadIdx.x == 0) trace[4 * it + 2] = __builtin_amdgcn_s_memrealtime();
+        if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         if (last_band) {
             // The last band of a job is the last one to finish, and every cell of the job is written through to memory
             // by now: this worker walks the traceback (all four wavefronts; helpers of a chain-only job join here).
@@ -1118,9 +1298,9 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
             __syncthreads();
             if (tb_go != 0 && !(DUMMY & 8)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
-                pgm_traceback_job(J, L.t, (int)threadIdx.x, 256);
+                pgm_traceback_job(J, L.t, (int)threadIdx.x, 256, trace ? trace + 6 * it + 4 : nullptr);
             }
-            if (trace && threadIdx.x == 0) trace[4 * it + 3] = __builtin_amdgcn_s_memrealtime();
+            if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
             // the ring's "column < 0" slots must read as zero again for the next band
             __syncthreads();
             if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -59,7 +59,7 @@ struct DevLayout {  // sizes of device-only regions
 struct pgm_align_batch {
     uint32_t njobs = 0;
     uint64_t cells = 0;
-    uint32_t maxdim = 0, maxnb = 0;
+    uint32_t maxdim = 0, maxnb = 0, maxn = 0;
     std::vector<PgmJob> jobs;         // host copy of the descriptors (device pointers inside)
     std::vector<uint32_t> order;      // launch order: largest job first
     uint8_t *d_in = nullptr;          // uploaded inputs (arena image)
@@ -208,7 +208,9 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipError_t e;
     if (timed && (e = hipEventRecord(b->ev[0], s)) != hipSuccess) return e;
     const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim) * sizeof(float);
-    hipLaunchKernelGGL(pgm_prep_kernel, dim3(b->njobs, 2), dim3(256), prep_lds, s, b->d_jobs);
+    const dim3 pg(b->njobs, 2, (b->maxn + 255) / 256);
+    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_prep_kernel<20>), pg, dim3(256), prep_lds, s, b->d_jobs);
+    else hipLaunchKernelGGL((pgm_prep_kernel<64>), pg, dim3(256), prep_lds, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
     const dim3 eg((b->maxnblk + 3) / 4, b->maxnb, b->njobs);
@@ -262,6 +264,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.nblk = (J.tsteps + PGM_BLOCK - 1) / PGM_BLOCK;
         b->maxnblk = std::max(b->maxnblk, J.nblk);
         J.maxn = std::max(a->n, c->n);
+        b->maxn = std::max(b->maxn, J.maxn);
         J.sc = scores[i];
         b->maxdim = std::max(b->maxdim, a->dim);
         b->maxnb = std::max(b->maxnb, J.nb);
@@ -343,12 +346,14 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
             const double tau = J.has_extras ? 0.65 : 0.38;      // us per step
-            const double tb = 0.35 * (double)(J.n1 + J.n2);      // the traceback follows the last band (us)
+            const double tb = 0.8 * (double)(J.n1 + J.n2);       // the traceback follows the last band (us)
             for (uint32_t band = 0; band < J.nb; ++band) keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb, i, band});
         }
         std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.rem > y.rem; });
         items.reserve(keys.size());
-        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band});
+        // wave priority (s_setprio) of a band: the longest paths of the batch win the issue arbitration on their SIMDs
+        const double rmax = keys.empty() ? 1.0 : keys.front().rem;
+        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band, k.rem > 0.6 * rmax ? 3u : (k.rem > 0.35 * rmax ? 2u : (k.rem > 0.2 * rmax ? 1u : 0u)), 0u});
     }
     b->nitems = (uint32_t)items.size();
     {
@@ -357,7 +362,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }
-    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 32 * items.size());
+    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 48 * items.size());
     if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -419,9 +424,9 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
-        std::vector<unsigned long long> tr(4 * (size_t)b->nitems);
+        std::vector<unsigned long long> tr(6 * (size_t)b->nitems);
         std::vector<PgmItem> its(b->nitems);
-        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 32 * (size_t)b->nitems, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 48 * (size_t)b->nitems, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(its.data(), b->d_items, sizeof(PgmItem) * b->nitems, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(getenv("PGM_FILL_TRACE") ? getenv("PGM_FILL_TRACE") : "/dev/null", "wb")) {
             fwrite(&b->nitems, 4, 1, f); fwrite(its.data(), sizeof(PgmItem), b->nitems, f); fwrite(tr.data(), 8, tr.size(), f); fclose(f);

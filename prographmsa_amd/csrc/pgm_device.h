@@ -93,6 +93,7 @@ struct PgmJob {
 // band b-1 (workers take the bands in list order, see pgm_fill_kernel).
 struct PgmItem {
     uint32_t job, band;
+    uint32_t prio, pad;   // prio: wave priority 0..3 while the band (and a traceback that follows it) is processed
 };
 
 #endif

@@ -18,8 +18,9 @@ b = J.Batch(ctx, jobs)
 b.run(); b.fetch(); b.run(); b.fetch()
 buf = open(trace, "rb").read()
 n = np.frombuffer(buf, np.uint32, 1)[0]
-items = np.frombuffer(buf, np.uint32, 2 * n, 4).reshape(n, 2)
-tr = np.frombuffer(buf, np.uint64, 4 * n, 4 + 8 * n).reshape(n, 4).astype(np.float64)
+items = np.frombuffer(buf, np.uint32, 4 * n, 4).reshape(n, 4)[:, :2]
+raw = np.frombuffer(buf, np.uint64, 6 * n, 4 + 16 * n).reshape(n, 6)
+tr = raw[:, :4].astype(np.float64)
 t0 = tr[:, 1].min()
 start, bend, tend = (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0, np.where(tr[:, 3] > 0, (tr[:, 3] - t0) / 100.0, 0)   # us
 end = np.maximum(bend, tend)
@@ -35,6 +36,16 @@ late = np.argsort(-end)[:12]
 for i in late:
     j, bd = items[i]
     print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 47) // 48, start[i], bend[i], tend[i]))
+tbi = np.where(tend > 0)[0]
+rel = raw[tbi, 4].astype(np.float64) / 100.0
+nrel = (raw[tbi, 5] >> np.uint64(32)).astype(np.float64)
+slow = (raw[tbi, 5] & np.uint64(0xffffffff)).astype(np.float64)
+plen = np.array([sizes[items[i, 0]].sum() for i in tbi], dtype=np.float64)
+for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs[items[i, 0]].g1.n - 1 and jobs[items[i, 0]].g2.e_col.size == jobs[items[i, 0]].g2.n - 1 for i in tbi])),):
+    for nm, mm in ((name, m), ("merged", ~m)):
+        if mm.any():
+            print("traceback %-10s: %3d jobs, mean %.0f us, of which tile staging %.0f us in %.0f tiles (%.1f us/tile); slow steps %.0f of ~%.0f nodes; walking %.3f us/node" % (
+                nm, mm.sum(), tb[tbi][mm].mean(), rel[mm].mean(), nrel[mm].mean(), (rel[mm] / nrel[mm]).mean(), slow[mm].mean(), plen[mm].mean(), ((tb[tbi][mm] - rel[mm]) / plen[mm]).mean()))
 # per-job: first start, last end
 for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
