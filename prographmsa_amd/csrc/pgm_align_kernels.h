@@ -275,7 +275,7 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 }
 
 #define PGM_TB_T 32        // tile edge (rows and columns)
-#define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's
+#define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's (half of it for chain-only jobs)
 #define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
 struct PgmTbLds {
     float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
@@ -346,6 +346,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             T.cell[i] = cv[u];
             T.S[i] = sv[u];
         }
+        for (uint32_t i = (uint32_t)tid; i < 3u * TT * TT / 2u; i += 256u) ((uint32_t *)T.succ)[i] = 0u;   // no links yet
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
@@ -363,14 +364,19 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
     const pgm_scores sc = J.sc;
     // Only for the cells within PGM_TB_BAND diagonals of the walker's position (T.ay, T.ax) when the tile was requested:
     // an alignment path mostly runs along that diagonal; off the band the walker asks for a new tile.
+    const int band = J.has_extras ? PGM_TB_BAND : PGM_TB_BAND / 2;   // alignments of merged graphs wander more (gaps)
     auto links = [&]() {
         const uint32_t ty0 = T.ty0, tx0 = T.tx0;
         const int adiag = (int)(T.ay - ty0) - (int)(T.ax - tx0);
-        for (uint32_t ci = (uint32_t)tid; ci < TT * TT; ci += (uint32_t)nthreads) {
-            const uint32_t ly = ci / TT, lx = ci % TT, y = ty0 + ly, x = tx0 + lx;
+        // one task = (state, diagonal of the band, position on it); a thread's tasks mix the three states
+        const uint32_t NDIAG = 2u * (uint32_t)band + 1u;
+        for (uint32_t task = (uint32_t)tid; task < 3u * NDIAG * TT; task += (uint32_t)nthreads) {
+            const uint32_t lx = task % TT, st_task = task / (NDIAG * TT);
+            const int lyi = (int)lx + adiag + (int)((task / TT) % NDIAG) - band;
+            if (lyi < 0 || lyi >= (int)TT) continue;
+            const uint32_t ly = (uint32_t)lyi, ci = ly * TT + lx, y = ty0 + ly, x = tx0 + lx;
             uint16_t lm = 0, lxs = 0, lys = 0;
-            const int off = (int)ly - (int)lx - adiag;
-            if (y + 1 < n1 && x + 1 < n2 && (y | x) != 0u && off >= -PGM_TB_BAND && off <= PGM_TB_BAND) {
+            if (y + 1 < n1 && x + 1 < n2 && (y | x) != 0u) {
                 const float4 c0 = T.cell[ci];
                 const uint32_t cy = T.p_cnt[ly], cx = T.p_cnt[TT + lx];
                 const bool oky = cy <= PGM_TB_PK, okx = cx <= PGM_TB_PK;
@@ -384,7 +390,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     return (uint16_t)(0x8000u | (st << 10) | ((yp - ty0) << 5) | (xp - tx0));
                 };
                 // state M: pairs (row predecessor outer, column predecessor inner)
-                if (oky && okx && c0.x > PGM_NEG_INF) {
+                if (st_task == 0u && oky && okx && c0.x > PGM_NEG_INF) {
                     const float S = T.S[ci];
                     float best = INFINITY;
                     bool ok = true, rep_edge = false;
@@ -406,7 +412,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     if (ok && best < INFINITY && !rep_edge) lm = pick(wc, wy, wx);
                 }
                 // state Y: row predecessors, extension before opening
-                if (oky && c0.w > PGM_NEG_INF) {
+                if (st_task == 2u && oky && c0.w > PGM_NEG_INF) {
                     float best = INFINITY;
                     bool ok = true, rep_edge = false, open = false;
                     uint32_t wy = 0;
@@ -426,7 +432,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                         lys = open ? pick(wc, wy, x) : (uint16_t)(0x8000u | (2u << 10) | ((wy - ty0) << 5) | lx);
                 }
                 // state X: column predecessors
-                if (okx && c0.y > PGM_NEG_INF) {
+                if (st_task == 1u && okx && c0.y > PGM_NEG_INF) {
                     float best = INFINITY;
                     bool ok = true, rep_edge = false, open = false;
                     uint32_t wx = 0;
@@ -446,7 +452,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                         lxs = open ? pick(wc, y, wx) : (uint16_t)(0x8000u | (1u << 10) | (ly << 5) | (wx - tx0));
                 }
             }
-            T.succ[ci] = lm; T.succ[TT * TT + ci] = lxs; T.succ[2 * TT * TT + ci] = lys;
+            T.succ[st_task * (TT * TT) + ci] = st_task == 0u ? lm : (st_task == 1u ? lxs : lys);
         }
     };
     if (tid == 0) {
@@ -581,7 +587,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             // new tile when the walker is near the low edge of the current one (or outside it, after a far edge)
             const int offb = ((int)(y - ty0) - (int)(x - tx0)) - adiag;
             if (((y - ty0) >= TT || ((y - ty0) < margin && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < margin && tx0 != 0)) ||
-                ((offb < -PGM_TB_BAND || offb > PGM_TB_BAND) && (y != ay || x != ax))) {
+                ((offb < -band || offb > band) && (y != ay || x != ax))) {
                 ty0 = y >= TT - 1 ? y - (TT - 1) : 0u;
                 tx0 = x >= TT - 1 ? x - (TT - 1) : 0u;
                 const unsigned long long r0 = stat ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -594,21 +600,27 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 __syncthreads();        // successor table complete
                 if (stat) { st_reload += __builtin_amdgcn_s_memrealtime() - r0; ++st_nreload; }
             }
-            // fast path: follow the precomputed link of (cell, state)
+            // fast path: follow the precomputed links.  A link's low 12 bits are the table index of the next (state, cell),
+            // so the chase is one LDS read per step; it ends at the first (cell, state) without a link (off the band, near
+            // the tile's low edge, repeat edge, ...), which the code below handles.
             if (in_tile(y, x)) {
-                const uint32_t code = T.succ[(uint32_t)(current_state == State_m ? 0 : (current_state == State_x ? 1 : 2)) * (TT * TT) + (y - ty0) * TT + (x - tx0)];
-                if (code & 0x8000u) {
-                    y = ty0 + ((code >> 5) & 31u); x = tx0 + (code & 31u);
-                    const uint32_t st = (code >> 10) & 3u;
+                uint32_t pos = (uint32_t)(current_state == State_m ? 0 : (current_state == State_x ? 1 : 2)) * (TT * TT) + (y - ty0) * TT + (x - tx0);
+                bool moved = false;
+                for (;;) {
+                    const uint32_t code = T.succ[pos];
+                    if (!(code & 0x8000u)) break;
+                    pos = code & 0xfffu;
+                    moved = true;
+                    const uint32_t ny = ty0 + ((pos >> 5) & 31u), nx = tx0 + (pos & 31u), st = pos >> 10;
+                    if ((ny | nx) == 0u) break;
+                    if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = st == 1u ? 0xFFFFFFFFu : ny; mo.m2[mo.len] = st == 2u ? 0xFFFFFFFFu : nx; }
+                    ++mo.len;
+                }
+                if (moved) {
+                    y = ty0 + ((pos >> 5) & 31u); x = tx0 + (pos & 31u);
+                    const uint32_t st = pos >> 10;
                     current_state = st == 0u ? State_m : (st == 1u ? State_x : State_y);
                     score_stale = true;
-                    if (x != 0 || y != 0) {
-                        uint32_t py = y, px = x;
-                        if (current_state == State_x) py = 0xFFFFFFFFu;
-                        else if (current_state == State_y) px = 0xFFFFFFFFu;
-                        if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = py; mo.m2[mo.len] = px; }
-                        ++mo.len;
-                    }
                     continue;
                 }
             }

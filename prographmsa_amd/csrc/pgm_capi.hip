@@ -357,8 +357,10 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     }
     b->nitems = (uint32_t)items.size();
     {
-        // persistent workers: 3 workgroups of 4 wavefronts per CU (150 VGPRs, 40 KB LDS each)
-        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 3u;
+        // persistent workers: up to 3 workgroups of 4 wavefronts fit a CU (168 VGPRs, 38 KB LDS each), but co-resident
+        // workers slow each other down (LDS traffic): on the 256 x 1000 batch 2.5 per CU gives the shortest makespan
+        // (measured 7.25 / 6.95 / 7.23 ms at 2 / 2.5 / 3 per CU, tools/probe_trace.py)
+        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 5u / 2u;
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }

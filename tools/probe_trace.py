@@ -46,6 +46,8 @@ for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs
         if mm.any():
             print("traceback %-10s: %3d jobs, mean %.0f us, of which tile staging %.0f us in %.0f tiles (%.1f us/tile); slow steps %.0f of ~%.0f nodes; walking %.3f us/node" % (
                 nm, mm.sum(), tb[tbi][mm].mean(), rel[mm].mean(), nrel[mm].mean(), (rel[mm] / nrel[mm]).mean(), slow[mm].mean(), plen[mm].mean(), ((tb[tbi][mm] - rel[mm]) / plen[mm]).mean()))
+ri = [k for k, i in enumerate(tbi) if items[i, 0] == np.argmax(sizes[:, 0] * sizes[:, 1])][0]
+print("root traceback: %.0f us, tile staging %.0f us in %.0f tiles (%.1f us/tile), slow steps %.0f" % (tb[tbi][ri], rel[ri], nrel[ri], rel[ri] / nrel[ri], slow[ri]))
 # per-job: first start, last end
 for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
