@@ -8,7 +8,8 @@ Workload (config.workload): the 255 graph-vs-graph alignGraphs jobs of one progr
 256 x 1000 aa family (tests/gen.py seed 3, guide tree tests/golden/c3.tree, --mldist), 2.71e8 DP cells, exactly the
 jobs the product driver issues (captured with `pgmsa --dump_jobs` on this GPU during untimed set-up).
 One "step" = one pass of the hot path over that batch with the inputs resident in HBM: prep (float casts,
-T = M^T g2) + emission scores + DP fill + traceback kernels, then the result/mapping copy back to the host.
+T = M^T g2) + emission scores + the fill kernel (DP fill of every band and, after a job's last band, its traceback),
+then the result/mapping copy back to the host.
 Multi-GPU: one process per GPU, every rank runs the same workload on its own device (independent jobs, no collective
 on the data path; weak scaling); torch.distributed is used only for the barrier and the max-over-ranks clock.
 """
@@ -105,13 +106,21 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         dt, total_cells = float(t.item()), float(c.item())
 
-    # ---- roofline of the dominant kernel (fill), HIP events on the library's stream ---------------
-    ms_prep, ms_emis, ms_fill, ms_tb = batch.time(5)
-    alg_bytes = 16.0 * cells            # one float4 {M,X,Y,W} store per cell, S fused
-    achieved = alg_bytes / (ms_fill * 1e-3) / 1e9
+    # ---- roofline of the dominant kernel (pgm_fill_kernel: DP fill + tracebacks), HIP events on the library's stream ----
+    ms_prep, ms_emis, ms_fill, _ = batch.time(5)
+    alg_bytes = 16.0 * cells            # one float4 {M,X,W,Y} store per cell; S is materialised by the emission
+    achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
+    # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v9_pmc.json")
+    if headline and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get("pgm_fill_kernel<0>", {})
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
-                "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill": round(ms_fill, 4), "traceback": round(ms_tb, 4)},
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
+                "traffic_source": "profiles/r1_v9_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
+                "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4)},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
 
     # ---- all-pairs stage (DistanceFactoryAlign, `-a`): the 32 640 alignPair jobs of the same family, sharded over the

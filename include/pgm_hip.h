@@ -98,7 +98,7 @@ int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 
 /* Staged form of the same call (what pgm_align_graphs_batch does internally):
  *   create  : flatten + upload every job's inputs to HBM, allocate the DP storage
- *   run     : launch prep + emission + fill + traceback kernels on the context's stream (asynchronous)
+ *   run     : launch the prep, emission and fill(+traceback) kernels on the context's stream (asynchronous)
  *   fetch   : wait, copy score / mappings back into caller memory
  * bench.py times `run` with the inputs already resident. */
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
@@ -110,10 +110,9 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);
 /* Σ (n1-2)(n2-2) over the jobs of the batch (the GCUPS numerator). */
 uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
 /* Run the batch `reps` times back to back and return the mean device time in milliseconds of
- * each kernel stage (prep, emission scores, DP fill, traceback), measured with HIP events on
- * the context's stream.  The traceback kernel runs on a second stream concurrently with the fill
- * (each job is walked as soon as its last band is complete); ms_traceback is the tail that is
- * left after the fill kernel has ended. */
+ * each kernel stage (prep, emission scores, fill), measured with HIP events on the context's
+ * stream.  The tracebacks run inside the fill kernel (the worker that completes a job's last
+ * band walks that job's path), so ms_fill includes them and ms_traceback is ~0. */
 int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
                          float *ms_emission, float *ms_fill, float *ms_traceback);
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
@@ -144,7 +143,8 @@ float pgm_nw_last_kernel_ms(pgm_ctx *ctx);
  * [k][col][symbol]; centre: K x 20 doubles = profiles_k.row(center); priors: K doubles
  * (= log(PRIOR)).  create: for each sequence (symbols 0..19, 20 = invalid) writes the
  * 20 x (L+2) column-major double profile of Model<AA>::Profile into out + out_offs[s].
- * tau[s] = model.divergence/0.8; pi = model.pi (20); p_uniform = model.P * (1/20) (20). */
+ * tau[s] = model.divergence/0.8; pi = model.pi (20); p_uniform = model.P * (1/20), one vector of
+ * 20 per sequence (nseq x 20, each leaf has its own model). */
 int pgm_csprofile_load(pgm_ctx *ctx, uint32_t K, uint32_t ncols, const double *lprofiles,
                        const double *centre, const double *priors);
 int pgm_csprofile_create_batch(pgm_ctx *ctx, uint32_t nseq, const int8_t *syms,
