@@ -66,7 +66,8 @@ struct pgm_align_batch {
     uint8_t *d_work = nullptr;        // prep outputs, brow, maps, results, scratch
     uint8_t *d_cells = nullptr;       // DP storage
     uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
-    std::vector<uint8_t> h_out;
+    uint8_t *h_out = nullptr;          // pinned staging buffer of the result block (one D2H copy per fetch)
+    int *h_flag = nullptr;
     uint8_t *d_S = nullptr;           // emission scores in fill order
     int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
     size_t sync_ints = 0, s_bytes = 0;
@@ -364,6 +365,11 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }
+    if ((e = hipHostMalloc((void **)&b->h_out, b->out_bytes, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
     if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 48 * items.size());
     if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
@@ -414,15 +420,14 @@ int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_p
 int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) {
     if (!ctx || !b || (b->njobs && !out)) return fail(PGM_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (b->njobs == 0) return PGM_OK;
-    // results + mappings live in one contiguous device region: a single D2H copy, then scatter
+    if (b->njobs == 0) { HIPCHK(hipStreamSynchronize(ctx->stream)); return PGM_OK; }
+    // results + mappings live in one contiguous device region: a single D2H copy into pinned memory (stream ordered
+    // behind the kernels), then scatter
     int rc = PGM_OK;
-    b->h_out.resize(b->out_bytes);
-    int aborted = 0;
-    HIPCHK(hipMemcpyAsync(b->h_out.data(), b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&aborted, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b->h_flag, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int aborted = *b->h_flag;
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
@@ -436,7 +441,7 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     }
     for (uint32_t i = 0; i < b->njobs; ++i) {
         PgmJob::Result res;
-        memcpy(&res, b->h_out.data() + b->res_off[i], sizeof res);
+        memcpy(&res, b->h_out + b->res_off[i], sizeof res);
         out[i].score = res.score;
         out[i].n_tr_indels = res.n_tr_indels;
         out[i].len = res.len;
@@ -444,8 +449,8 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
         if (res.status != PGM_OK) rc = res.status;
         if (!out[i].map1 || !out[i].map2) return fail(PGM_ERR_INVALID, "null mapping buffer");
         if (res.len > b->jobs[i].n1 + b->jobs[i].n2) return fail(PGM_ERR_DEVICE, "corrupt result length");
-        memcpy(out[i].map1, b->h_out.data() + b->map1_off[i], 4 * (size_t)res.len);
-        memcpy(out[i].map2, b->h_out.data() + b->map2_off[i], 4 * (size_t)res.len);
+        memcpy(out[i].map1, b->h_out + b->map1_off[i], 4 * (size_t)res.len);
+        memcpy(out[i].map2, b->h_out + b->map2_off[i], 4 * (size_t)res.len);
     }
     if (rc != PGM_OK) g_err = "backtracking failed";
     return rc;
@@ -462,6 +467,8 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (b->d_out) (void)hipFree(b->d_out);
     if (b->d_S) (void)hipFree(b->d_S);
     if (b->d_sync) (void)hipFree(b->d_sync);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_flag) (void)hipHostFree(b->h_flag);
     if (b->d_items) (void)hipFree(b->d_items);
     if (b->d_trace) (void)hipFree(b->d_trace);
     if (b->d_jobs) (void)hipFree(b->d_jobs);

@@ -182,7 +182,8 @@ class Batch:
 
 # -------------------------------------------------------------------------------------------------
 # Synthetic jobs for parity tests: random DAGs with skip edges, unreachable-cost edges and repeat edges.
-def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, drop_chain_frac=0.03):
+def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, drop_chain_frac=0.03, skip_span=12, skip_max=3,
+                 repeat_span=20):
     sites = np.zeros((n, dim))
     for i in range(1, n - 1):
         if rng.random() < onehot_frac:
@@ -198,8 +199,8 @@ def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, 
             if rng.random() >= drop_chain_frac or v == 1:
                 preds[v - 1] = 0.0
             if v > 1 and rng.random() < skip_frac:
-                for _ in range(int(rng.integers(1, 4))):
-                    p = int(rng.integers(max(0, v - 12), v))
+                for _ in range(int(rng.integers(1, skip_max + 1))):
+                    p = int(rng.integers(max(0, v - skip_span), v))
                     c = float(rng.choice([0.0, 0.80369, 1.60738, 2.5, 7.25]))
                     preds[p] = min(preds.get(p, 1e9), c)
             if not preds:
@@ -209,7 +210,7 @@ def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, 
             val.append(np.float32(min(np.float32(preds[p]), np.float32(1e4))) - np.float32(1e4))
         rp.append(len(col))
         if v > 2 and rng.random() < repeat_frac:
-            p = int(rng.integers(max(0, v - 20), v - 1))
+            p = int(rng.integers(max(0, v - repeat_span), v - 1))
             rcol.append(p)
             ru.append(int(rng.integers(1, 4)))
         rrp.append(len(rcol))

@@ -29,6 +29,8 @@ def _cmp_job(batch, idx, job, res):
     dict(skip_frac=0.0, drop_chain_frac=0.0),                 # pure chains (leaf vs leaf)
     dict(skip_frac=0.2),                                      # merged-graph like skip edges
     dict(skip_frac=0.3, repeat_frac=0.05),                    # + tandem-repeat edges
+    dict(skip_frac=0.95, skip_max=9, drop_chain_frac=0.0),    # dense extras: > 128 row extras per band, > 7 per node (generic path)
+    dict(skip_frac=0.1, skip_span=70, repeat_frac=0.03, repeat_span=90),   # far edges: beyond the LDS history and the traceback tile
 ])
 def test_random_jobs_bit_exact(ctx, kw):
     from prographmsa_amd import jobs as J
