@@ -276,6 +276,7 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 
 #define PGM_TB_T 32        // tile edge (rows and columns)
 #define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's (half of it for chain-only jobs)
+#define PGM_TB_MAXPAIRS 12 // most candidate pairs of a cell for which an M-state link is precomputed
 #define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
 struct PgmTbLds {
     float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
@@ -390,7 +391,9 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     return (uint16_t)(0x8000u | (st << 10) | ((yp - ty0) << 5) | (xp - tx0));
                 };
                 // state M: pairs (row predecessor outer, column predecessor inner)
-                if (st_task == 0u && oky && okx && c0.x > PGM_NEG_INF) {
+                // (cells with many candidate pairs get no M link: one such cell would hold up the whole tile; the walker
+                // evaluates them itself, one pair per lane, if the path really visits them)
+                if (st_task == 0u && oky && okx && cy * cx <= PGM_TB_MAXPAIRS && c0.x > PGM_NEG_INF) {
                     const float S = T.S[ci];
                     float best = INFINITY;
                     bool ok = true, rep_edge = false;
@@ -776,7 +779,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
 // that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
 template <int DUMMY>
-__global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
+__global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace) {
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
     constexpr int NQ = 4;
@@ -798,14 +801,18 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
         int el_cnt;
         int lds_abort;
     };
-    __shared__ __attribute__((aligned(16))) union { FillLds f; PgmTbLds t; } L;
+    // chain-only jobs (no skip edges, no helpers): the four wavefronts sweep four consecutive bands of the job, each with
+    // its own ring / replay tile / score buffers
+    struct ChainLds {
+        float4 ring[R * NQ];
+        float2 rep[BL * HR];
+        float sblk[2 * BL * 64];
+    };
+    __shared__ __attribute__((aligned(16))) union { FillLds f; ChainLds c[4]; PgmTbLds t; } L;
     __shared__ int item_lds, tb_go;
-    float4 (&ring)[R * NQ] = L.f.ring;
     float (&hW)[HW * 64] = L.f.hW;
     float (&hY)[H * 64] = L.f.hY;
     float (&hX)[H * 64] = L.f.hX;
-    float2 (&rep)[BL * HR] = L.f.rep;
-    float (&sblk)[2 * BL * 64] = L.f.sblk;
     float (&res1)[2 * 2 * 64] = L.f.res1;
     float (&resA)[2 * 2 * 64] = L.f.resA;
     uint32_t (&el_a)[PGM_ENT] = L.f.el_a;
@@ -823,10 +830,8 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
-    if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
     for (;;) {
-        // next band of the list (all four wavefronts take the same one)
+        // next item of the list (all four wavefronts take the same one)
         __syncthreads();
         if (threadIdx.x == 0) {
             int it = -1;
@@ -845,11 +850,19 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
         // optional timeline (tools/probe_trace.py): per item {worker, start, end of band, end of traceback} in 100 MHz ticks
         if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
         const PgmJob &J = jobs[item.job];
-        const uint32_t b = item.band;
+        // Merged graphs: one band, wavefront 0 sweeps it, wavefronts 1..3 help.  Chain-only jobs ("pack"): item.count <= 4
+        // consecutive bands, wavefront w sweeps band item.band + w on its own (no barriers inside the sweep; the bands
+        // hand over through the cell storage like any two bands).
         const bool need_help = J.has_extras != 0;
-        const bool last_band = (b + 1 == J.nb);
-        if (role != 0 && !need_help && !last_band) continue;     // chain-only job: the main wavefront alone (no barriers inside the band)
-        if (role == 0 || need_help) {
+        const bool pack = !need_help;
+        const uint32_t b = item.band + (pack ? (uint32_t)role : 0u);
+        const bool last_band = (item.band + item.count == J.nb);
+        const bool sweeper = pack ? ((uint32_t)role < item.count) : (role == 0);   // this wavefront owns the chain of a band
+        if (!sweeper && !need_help && !last_band) continue;
+        float4 *ring = pack ? L.c[role].ring : L.f.ring;
+        float2 *rep = pack ? L.c[role].rep : L.f.rep;
+        float *sblk = pack ? L.c[role].sblk : L.f.sblk;
+        if (sweeper || need_help) {
         const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
         const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
         const bool comp = lane >= HR;
@@ -918,7 +931,8 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
             if (nxw > 4) cols_chunk(std::integral_constant<int, 4>(), std::integral_constant<int, PGM_KX>(), t8, cj8, cxv, S, Mn, Xn);
         };
 
-        if (role == 0) {
+        if (sweeper) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // "column < 0" slots
+        if (role == 0 && need_help) {
             for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
             for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
             for (int i = lane; i < 2 * 2 * 64; i += 64) resA[i] = PGM_NEG_INF;
@@ -943,7 +957,7 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
             }
         }
 
-        if (role == 0) {
+        if (sweeper) {
             // =========================================== main wavefront ===========================================
             float W_left = PGM_NEG_INF, X_left = PGM_NEG_INF, W_diag = PGM_NEG_INF;
             float W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
@@ -1150,7 +1164,7 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
                         W_left = Wv;
                         X_left = Xv;
                     }
-                    {
+                    if (need_help) {
                         const int ho = (int)((t & (H - 1)) << 6) + lane;
                         hW[ho] = Wv;
                         hY[ho] = Yv;
@@ -1173,7 +1187,7 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        } else if (need_help) {
             // =========================================== helper wavefronts ==========================================
             __syncthreads();   // matches the main wavefront's barrier after initialisation
             const int h = role - 1;
@@ -1313,9 +1327,6 @@ __global__ void __launch_bounds__(256, 3) pgm_fill_kernel(const PgmJob *__restri
                 pgm_traceback_job(J, L.t, (int)threadIdx.x, 256, trace ? trace + 6 * it + 4 : nullptr);
             }
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
-            // the ring's "column < 0" slots must read as zero again for the next band
-            __syncthreads();
-            if (role == 0) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }

@@ -341,27 +341,29 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // with the helper wavefronts, ~0.65 us).  Within a job the order is band 0, 1, 2, ... as the kernel requires.
     std::vector<PgmItem> items;
     if (njobs) {
-        struct Key { double rem; uint32_t job, band; };
+        struct Key { double rem; uint32_t job, band, count; };
         std::vector<Key> keys;
         const double lag = PGM_ROWS + 4.0 * PGM_BLOCK;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
             const double tau = J.has_extras ? 0.65 : 0.38;      // us per step
             const double tb = 0.8 * (double)(J.n1 + J.n2);       // the traceback follows the last band (us)
-            for (uint32_t band = 0; band < J.nb; ++band) keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb, i, band});
+            const uint32_t group = J.has_extras ? 1u : 4u;       // chain-only jobs: four bands per item, one per wavefront
+            for (uint32_t band = 0; band < J.nb; band += group)
+                keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb, i, band, std::min(group, J.nb - band)});
         }
         std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.rem > y.rem; });
         items.reserve(keys.size());
         // wave priority (s_setprio) of a band: the longest paths of the batch win the issue arbitration on their SIMDs
         const double rmax = keys.empty() ? 1.0 : keys.front().rem;
-        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band, k.rem > 0.6 * rmax ? 3u : (k.rem > 0.35 * rmax ? 2u : (k.rem > 0.2 * rmax ? 1u : 0u)), 0u});
+        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band, k.rem > 0.6 * rmax ? 3u : (k.rem > 0.35 * rmax ? 2u : (k.rem > 0.2 * rmax ? 1u : 0u)), k.count});
     }
     b->nitems = (uint32_t)items.size();
     {
-        // persistent workers: up to 3 workgroups of 4 wavefronts fit a CU (168 VGPRs, 38 KB LDS each), but co-resident
-        // workers slow each other down (LDS traffic): on the 256 x 1000 batch 2.5 per CU gives the shortest makespan
-        // (measured 7.25 / 6.95 / 7.23 ms at 2 / 2.5 / 3 per CU, tools/probe_trace.py)
-        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 5u / 2u;
+        // persistent workers: 2 workgroups of 4 wavefronts per CU.  A third would fit, but co-resident workers slow each
+        // other down (LDS traffic) and the batch's makespan is its longest job's critical path: measured on the 256 x 1000
+        // batch 7.3 / 6.6 / 7.0 ms at 1.5 / 2 / 2.5 per CU (tools/probe_trace.py)
+        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }

@@ -89,11 +89,12 @@ struct PgmJob {
 };
 
 
-// One unit of fill work: band `band` (48 rows) of job `job`.  The list is ordered so that band b of a job comes after
-// band b-1 (workers take the bands in list order, see pgm_fill_kernel).
+// One unit of fill work: `count` consecutive bands (48 rows each) of job `job`, starting at `band`: 1 for merged graphs
+// (one wavefront sweeps, three help), up to 4 for chain-only jobs (one band per wavefront).  The list is ordered so that
+// a job's bands come in ascending order (workers take the items in list order, see pgm_fill_kernel).
 struct PgmItem {
     uint32_t job, band;
-    uint32_t prio, pad;   // prio: wave priority 0..3 while the band (and a traceback that follows it) is processed
+    uint32_t prio, count; // prio: wave priority 0..3 while the item (and a traceback that follows it) is processed
 };
 
 #endif
