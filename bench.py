@@ -90,12 +90,15 @@ def main():
 
     for _ in range(args.warmup):
         batch.run()
-        batch.fetch()
+        batch.fetch_raw()
+    if args.warmup > 0:
+        check = batch.fetch()   # results of the last warm-up step as Python objects (sanity check)
+        assert all(r["status"] == 0 and len(r["map1"]) > 0 for r in check)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run()
-        batch.fetch()
+        batch.run()          # pgm_align_batch_run: prep + emission + fill/traceback kernels
+        batch.fetch_raw()    # pgm_align_batch_fetch: wait, D2H of scores and mappings into the caller's buffers
     barrier()
     dt = time.perf_counter() - t0
     total_cells = float(cells) * args.steps

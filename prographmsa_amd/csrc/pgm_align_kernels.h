@@ -396,9 +396,10 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 if (st_task == 0u && oky && okx && cy * cx <= PGM_TB_MAXPAIRS && c0.x > PGM_NEG_INF) {
                     const float S = T.S[ci];
                     float best = INFINITY;
-                    bool ok = true, rep_edge = false;
-                    uint32_t wy = 0, wx = 0;
-                    float4 wc = c0;
+                    bool ok = true;
+                    uint32_t wy = 0, wx = 0, wky = 0, wkx = 0;
+                    // the comparisons only need W of each candidate cell (one dword); the winner's full cell, its
+                    // repeat markers and the state decision are read once after the search
                     for (uint32_t ky = 0; ky < cy && ok; ++ky) {
                         const uint32_t yp = T.p_c[ly * PGM_TB_PK + ky];
                         const float yv = T.p_v[ly * PGM_TB_PK + ky];
@@ -407,15 +408,23 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                             const uint32_t xp = T.p_c[(TT + lx) * PGM_TB_PK + kx];
                             if (xp < tx0) { ok = false; break; }
                             const float xv = T.p_v[(TT + lx) * PGM_TB_PK + kx];
-                            const float4 c = T.cell[(yp - ty0) * TT + (xp - tx0)];
-                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
-                            if (best > d) { best = d; wy = yp; wx = xp; wc = c; rep_edge = (T.p_u[ly * PGM_TB_PK + ky] | T.p_u[(TT + lx) * PGM_TB_PK + kx]) != 0u; }
+                            const float wz = T.cell[(yp - ty0) * TT + (xp - tx0)].z;
+                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(wz, S), yv), xv)));
+                            if (best > d) { best = d; wy = yp; wx = xp; wky = ky; wkx = kx; }
                         }
+                    }
+                    bool rep_edge = false;
+                    float4 wc = c0;
+                    if (ok && best < INFINITY) {
+                        rep_edge = (T.p_u[ly * PGM_TB_PK + wky] | T.p_u[(TT + lx) * PGM_TB_PK + wkx]) != 0u;
+                        wc = T.cell[(wy - ty0) * TT + (wx - tx0)];
                     }
                     if (ok && best < INFINITY && !rep_edge) lm = pick(wc, wy, wx);
                 }
                 // state Y: row predecessors, extension before opening
-                if (st_task == 2u && oky && c0.w > PGM_NEG_INF) {
+                // (gap states are rare on a path: links only where they cost two candidates; other cells are evaluated by the
+                // walker if it really arrives there in a gap state)
+                if (st_task == 2u && cy == 1u && c0.w > PGM_NEG_INF) {
                     float best = INFINITY;
                     bool ok = true, rep_edge = false, open = false;
                     uint32_t wy = 0;
@@ -435,7 +444,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                         lys = open ? pick(wc, wy, x) : (uint16_t)(0x8000u | (2u << 10) | ((wy - ty0) << 5) | lx);
                 }
                 // state X: column predecessors
-                if (st_task == 1u && okx && c0.y > PGM_NEG_INF) {
+                if (st_task == 1u && cx == 1u && c0.y > PGM_NEG_INF) {
                     float best = INFINITY;
                     bool ok = true, rep_edge = false, open = false;
                     uint32_t wx = 0;

@@ -149,10 +149,14 @@ class Batch:
     def run(self):
         check(lib.pgm_align_batch_run(self.ctx.handle, self.handle), "pgm_align_batch_run")
 
-    def fetch(self):
+    def fetch_raw(self):
+        """The C-ABI call alone: score / mappings land in the caller buffers of self.cj (no Python result objects)."""
         rc = lib.pgm_align_batch_fetch(self.ctx.handle, self.handle, self.cj.out)
         if rc not in (0, 3):
             check(rc, "pgm_align_batch_fetch")
+
+    def fetch(self):
+        self.fetch_raw()
         return self.cj.results()
 
     def time(self, reps):
