@@ -908,13 +908,6 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
         constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
         const uint32_t lane4 = (uint32_t)lane * 4u;
-        auto load_cols = [&](const float4 *rc, const float4 aux, uint32_t (&cj8)[PGM_KX], float (&cxv)[PGM_KX]) {
-            const float4 q1 = rc[1], q2 = rc[2], q3 = rc[3];
-            cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
-            cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
-            cj8[6] = __float_as_uint(q2.x);
-            cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
-        };
         // The history is read in batches: inside a chunk nothing is conditional (an absent extra has
         // distance 0 and cost +inf, so its term is -inf whatever the slot holds), which lets all LDS reads of the chunk be
         // issued back to back instead of one LDS round trip per term.
@@ -1204,26 +1197,32 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
             if (h == 0) {
                 // ---- helper 1: column extras, one row per lane like the main wavefront -----------------------------
+                // The column summary and the score of step t + 1 are read before the barrier of step t (they do not
+                // depend on the history), so after the barrier only the history reads remain.
+                float4 n_aux = ring[xr * NQ], n_q1 = ring[xr * NQ + 1], n_q2 = ring[xr * NQ + 2], n_q3 = ring[xr * NQ + 3];
+                float n_S = sblk[lane];
                 for (uint32_t t = 0; t < tend; ++t) {
-                    const float4 *rc = ring + xr * NQ;
-                    xr = (xr + 1 == R) ? 0 : xr + 1;
-                    const float4 aux = rc[0];
-                    const float S = sblk[((t / BL) & 1u) * (BL * 64) + (t % BL) * 64 + lane];
+                    const float4 aux = n_aux, q1 = n_q1, q2 = n_q2, q3 = n_q3;
+                    const float S = n_S;
                     const uint32_t fx = __float_as_uint(aux.y);
                     const int nxw = pgm_wave_max8(fx & 7u);
                     const uint32_t t8 = t << 8;
                     float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF;
                     uint32_t cj8[PGM_KX];
                     float cxv[PGM_KX];
-                    if (nxw > 0) load_cols(rc, aux, cj8, cxv);
-                    const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-                    const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
+                    cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
+                    cj8[6] = __float_as_uint(q2.x);
+                    cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
                     if (!(DUMMY & 1) && nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
                     float *rs = res1 + (t & 1u) * (2 * 64) + lane;
                     rs[0] = Mn; rs[64] = Xn;
+                    xr = (xr + 1 == R) ? 0 : xr + 1;
+                    n_aux = ring[xr * NQ]; n_q1 = ring[xr * NQ + 1]; n_q2 = ring[xr * NQ + 2]; n_q3 = ring[xr * NQ + 3];
+                    n_S = sblk[(((t + 1) / BL) & 1u) * (BL * 64) + ((t + 1) % BL) * 64 + lane];
                     const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb + (hc1 - hc0) * 0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             } else {
                 // ---- helpers 2 and 3: one ROW EXTRA (entry) per lane -----------------------------------------------
@@ -1249,13 +1248,14 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     e_lk4[p] = e_l[p] * 4u - (e_rk8[p] >> 6);
                     e_xr[p] = (R - (int)e_l[p]) % R;
                 }
-                for (uint32_t t = 0; t < tend; ++t) {
-                    const uint32_t t8 = t << 8;
+                // column data and score of the owner's next column are read before the barrier (see helper 1)
+                float S[2], ccx[2], gopen_y[2];
+                uint32_t dj[2][4];
+                float cxs[2][4];
+                bool any = false;
+                auto fetch_cols = [&](uint32_t t) {
                     const float *sb = sblk + ((t / BL) & 1u) * (BL * 64) + (t % BL) * 64;
-                    float S[2], ccx[2], gopen_y[2];
-                    uint32_t dj[2][4];
-                    float cxs[2][4];
-                    bool any = false;
+                    any = false;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         if (p == 0 || two) {
@@ -1279,9 +1279,11 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                             }
                         }
                     }
+                };
+                fetch_cols(0);
+                for (uint32_t t = 0; t < tend; ++t) {
+                    const uint32_t t8 = t << 8;
                     const bool work = __builtin_amdgcn_ballot_w64(any) != 0;
-                    const unsigned long long hc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
-                    const unsigned long long hc1 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     if (work && !(DUMMY & (h == 1 ? 2 : 4))) {
                         float *ra = resA + (t & 1u) * (2 * 64);
 #pragma unroll
@@ -1308,9 +1310,10 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                             }
                         }
                     }
+                    fetch_cols(t + 1);
                     const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
                     tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb + (hc1 - hc0) * 0; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             }
             if ((DUMMY & 8) && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
