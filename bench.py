@@ -186,15 +186,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib   # test-only CPU restatement, used here solely as the reported CPU baseline
-            sample = jobs[::2]
             tc = time.perf_counter()
-            for j in sample:
-                oracle_lib.align_graphs(j)
+            passes, ccells = 0, 0
+            while passes == 0 or (time.perf_counter() - tc < 10.0 and passes < 8):
+                for j in jobs:
+                    oracle_lib.align_graphs(j)
+                passes += 1
+                ccells += sum(j.cells for j in jobs)
             cdt = time.perf_counter() - tc
-            ccells = sum(j.cells for j in sample)
             out["cpu_baseline"] = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": 1, "kind": "port",
-                                   "sample": "every 2nd job of the same batch (%d jobs, %.3e cells, %.1f s), oracle/pgm_oracle.c -O2, 1 thread"
-                                             % (len(sample), ccells, cdt)}
+                                   "sample": "%d pass(es) over the same %d-job batch (%.3e cells, %.1f s), oracle/pgm_oracle.c -O2, 1 thread"
+                                             % (passes, len(jobs), ccells, cdt)}
         print(json.dumps(out))
     batch.close()
     ctx.close()
