@@ -109,37 +109,48 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 // Emission kernel (GraphAlign.h:145-163 precomputeScores, fused with ls_log_add): S for every cell, written
 // in the skewed (band, step, lane) order in which the fill kernel consumes it.  No dependencies between
 // cells, so this part of the reference's per-cell work runs at full occupancy, off the DP's critical path.
-// grid = (nblk chunks of 4 blocks, nb, njobs); block = 256 threads = 4 wavefronts, wavefront w owns the
-// 16-step block 4*blockIdx.x + w of band blockIdx.y; lane l >= 16 owns row y = 48 b + l - 16 and computes
-// its 16 cells (columns t - l).  The 127 columns of T = M^T g2 the workgroup touches are staged in LDS.
+// grid = (ceil(nblk / 4), ceil(nb / 4), njobs); block = 192 threads: thread T owns row T % 48 of band 4 blockIdx.y + T / 48
+// (no idle replay lanes here) and computes its cells of PGM_EM_TB = 4 step blocks (columns t - l, l = 16 + T % 48).
+// The 79 columns of T = M^T g2 the workgroup touches are staged in LDS as overlapping column PAIRS
+// {T[c][k], T[c+1][k]}: two consecutive cells of a row are then one packed multiply and one packed add per k
+// (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, the same sequential mul-then-add order as the scalar code).
+#define PGM_EM_TB 4   // step blocks per emission workgroup
 template <int DP>
-__global__ void __launch_bounds__(256) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
+__global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
+    typedef float pgm_v2f __attribute__((ext_vector_type(2)));
     constexpr int NT = DP / 4;
-    constexpr int COLS = 64 + 4 * PGM_BLOCK - 1;   // columns [t0 - 63, t0 + 63]
-    __shared__ float4 tq[COLS * NT];
+    constexpr int COLS = 64 + PGM_EM_TB * PGM_BLOCK - PGM_HALO - 1;   // columns [t0 - 63, t0 + PGM_EM_TB * PGM_BLOCK - 1 - 16]
+    __shared__ pgm_v2f tp[(COLS + 1) * DP];      // tp[c * DP + k] = {T[c][k], T[c+1][k]} (row COLS is scratch)
     __shared__ float bq[COLS];
     const PgmJob &J = jobs[blockIdx.z];
-    const uint32_t b = blockIdx.y;
-    if (b >= J.nb) return;
-    const uint32_t t0 = blockIdx.x * 4u * PGM_BLOCK;
-    if (t0 >= J.tsteps) return;
+    const uint32_t tb0 = blockIdx.x * PGM_EM_TB;
+    if (tb0 >= J.nblk || 4u * blockIdx.y >= J.nb) return;
+    const uint32_t t0 = tb0 * PGM_BLOCK;
     const int cbase = (int)t0 - 63;
+    // one float4 load per (column, 4 k): the value T[c][k] is the low half of pair c and the high half of pair c - 1
     const float4 *t2q = (const float4 *)J.t2;
-    for (int i = threadIdx.x; i < COLS * NT; i += 256) {
-        const int col = cbase + i / NT;
+    float *tpf = (float *)tp;
+    for (int i = threadIdx.x; i < (COLS + 1) * NT; i += 192) {
+        const int ci = i / NT, q = i % NT, c = cbase + ci;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col >= 0 && col <= (int)J.ncol) v = t2q[(size_t)NT * col + (i % NT)];
-        tq[i] = v;
+        if (c >= 0 && c <= (int)J.ncol) v = t2q[(size_t)NT * c + q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * q + u;
+            if (ci < COLS) tpf[2 * (ci * DP + k)] = vv[u];
+            if (ci > 0) tpf[2 * ((ci - 1) * DP + k) + 1] = vv[u];
+        }
     }
-    for (int i = threadIdx.x; i < COLS; i += 256) {
+    for (int i = threadIdx.x; i < COLS; i += 192) {
         const int col = cbase + i;
         bq[i] = (col >= 0 && col <= (int)J.ncol) ? J.b2[col] : 0.f;
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tb = blockIdx.x * 4u + wave;
-    if (tb >= J.nblk || lane < PGM_HALO) return;
-    const uint32_t y = PGM_ROWS * b + (uint32_t)(lane - PGM_HALO);
+    const uint32_t b = 4u * blockIdx.y + threadIdx.x / PGM_ROWS;
+    const int l = PGM_HALO + (int)(threadIdx.x % PGM_ROWS);
+    if (b >= J.nb) return;
+    const uint32_t y = PGM_ROWS * b + (uint32_t)(l - PGM_HALO);
     const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
     float gy[DP];
     {
@@ -152,27 +163,28 @@ __global__ void __launch_bounds__(256) pgm_emission_skew_kernel(const PgmJob *__
     }
     const float ay = J.a1[yc];
     const float mi = J.sc.match_init;
-    float out[PGM_BLOCK];
+#pragma unroll 1
+    for (int w = 0; w < PGM_EM_TB; ++w) {
+        const uint32_t tb = tb0 + w;
+        if (tb >= J.nblk) break;
+        float out[PGM_BLOCK];
 #pragma unroll
-    for (int i = 0; i < PGM_BLOCK; ++i) {
-        const int t = (int)(tb * PGM_BLOCK) + i;
-        int ci = t - lane - cbase;            // index into the staged window, in [0, COLS) whenever x >= cbase
-        ci = ci < 0 ? 0 : (ci >= COLS ? COLS - 1 : ci);
-        const float4 *tc = tq + ci * NT;
-        float acc = 0.0f;
+        for (int i = 0; i < PGM_BLOCK; i += 2) {
+            const int ci = (int)(tb * PGM_BLOCK) + i - l - cbase;   // column of cell i in the staged window; cell i + 1: column ci + 1
+            const pgm_v2f *tc = tp + ci * DP;
+            pgm_v2f acc = {0.0f, 0.0f};
 #pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            const float4 tv = tc[q];
-            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q], tv.x));
-            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 1], tv.y));
-            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 2], tv.z));
-            acc = __fadd_rn(acc, __fmul_rn(gy[4 * q + 3], tv.w));
+            for (int k = 0; k < DP; ++k) {
+                const pgm_v2f g = {gy[k], gy[k]};
+                acc = acc + g * tc[k];
+            }
+            out[i] = pgm_emission_finish(acc.x, ay, bq[ci], mi);
+            out[i + 1] = pgm_emission_finish(acc.y, ay, bq[ci + 1], mi);
         }
-        out[i] = pgm_emission_finish(acc, ay, bq[ci], mi);
-    }
-    float4 *dst = (float4 *)(J.S + (((size_t)b * J.nblk + tb) * 64u + (uint32_t)lane) * PGM_BLOCK);
+        float4 *dst = (float4 *)(J.S + (((size_t)b * J.nblk + tb) * 64u + (uint32_t)l) * PGM_BLOCK);
 #pragma unroll
-    for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    }
 }
 
 // wave-uniform maximum of a per-lane value in 0..7 (three ballots, no cross-lane data movement)

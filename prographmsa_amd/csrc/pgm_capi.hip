@@ -214,9 +214,9 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     else hipLaunchKernelGGL((pgm_prep_kernel<64>), pg, dim3(256), prep_lds, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
-    const dim3 eg((b->maxnblk + 3) / 4, b->maxnb, b->njobs);
-    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20>), eg, dim3(256), 0, s, b->d_jobs);
-    else hipLaunchKernelGGL((pgm_emission_skew_kernel<64>), eg, dim3(256), 0, s, b->d_jobs);
+    const dim3 eg((b->maxnblk + PGM_EM_TB - 1) / PGM_EM_TB, (b->maxnb + 3) / 4, b->njobs);
+    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20>), eg, dim3(192), 0, s, b->d_jobs);
+    else hipLaunchKernelGGL((pgm_emission_skew_kernel<64>), eg, dim3(192), 0, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
