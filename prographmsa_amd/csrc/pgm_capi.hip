@@ -29,6 +29,11 @@ static int fail(int code, const std::string &m) { g_err = m; return code; }
 struct pgm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
+    // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
+    enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_SLOTS };
+    void *cache_ptr[C_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0};
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0;
     // context-profile library resident in HBM
@@ -66,6 +71,7 @@ struct pgm_align_batch {
     uint8_t *d_work = nullptr;        // prep outputs, brow, maps, results, scratch
     uint8_t *d_cells = nullptr;       // DP storage
     uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
+    size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // real sizes of the buffers taken from the context's cache
     uint8_t *h_out = nullptr;          // pinned staging buffer of the result block (one D2H copy per fetch)
     int *h_flag = nullptr;
     uint8_t *d_S = nullptr;           // emission scores in fill order
@@ -113,6 +119,8 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_lprofiles) (void)hipFree(ctx->cs_lprofiles);
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
+    for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
+        if (ctx->cache_ptr[k]) { if (k == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[k]); else (void)hipFree(ctx->cache_ptr[k]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -202,6 +210,30 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     o.pv = A.put(pv.data(), 4 * pv.size());
     o.pu = A.put(pu.data(), 4 * pu.size());
     return PGM_OK;
+}
+
+// take a buffer of at least `bytes` from the context's cache slot, or allocate one (device memory; slot C_HOST: pinned host)
+static hipError_t cache_take(pgm_ctx *ctx, int slot, size_t bytes, void **out, size_t *got) {
+    if (ctx->cache_ptr[slot] && ctx->cache_bytes[slot] >= bytes) {
+        *out = ctx->cache_ptr[slot]; *got = ctx->cache_bytes[slot];
+        ctx->cache_ptr[slot] = nullptr; ctx->cache_bytes[slot] = 0;
+        return hipSuccess;
+    }
+    if (ctx->cache_ptr[slot]) {   // too small: replace
+        if (slot == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]);
+        ctx->cache_ptr[slot] = nullptr; ctx->cache_bytes[slot] = 0;
+    }
+    *got = bytes;
+    return slot == pgm_ctx::C_HOST ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+}
+static void cache_give(pgm_ctx *ctx, int slot, void *p, size_t bytes) {
+    if (!p) return;
+    if (ctx && (!ctx->cache_ptr[slot] || ctx->cache_bytes[slot] < bytes)) {
+        if (ctx->cache_ptr[slot]) { if (slot == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]); }
+        ctx->cache_ptr[slot] = p; ctx->cache_bytes[slot] = bytes;
+    } else {
+        if (slot == pgm_ctx::C_HOST) (void)hipHostFree(p); else (void)hipFree(p);
+    }
 }
 
 static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
@@ -300,8 +332,11 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->s_bytes = std::max<size_t>(SL.bytes, 16);
     b->sync_ints = sync_ints;
     hipError_t e;
-    if ((e = hipMalloc((void **)&b->d_in, b->in_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_work, b->work_bytes)) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_cells, b->cell_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_out, b->out_bytes)) != hipSuccess || (e = hipMalloc((void **)&b->d_S, b->s_bytes)) != hipSuccess ||
+    if ((e = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN])) != hipSuccess ||
+        (e = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK])) != hipSuccess ||
+        (e = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS])) != hipSuccess ||
+        (e = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT])) != hipSuccess ||
+        (e = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S])) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_sync, sync_ints * sizeof(int))) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
         (e = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
@@ -367,7 +402,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
         b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     }
-    if ((e = hipHostMalloc((void **)&b->h_out, b->out_bytes, hipHostMallocDefault)) != hipSuccess ||
+    if ((e = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST])) != hipSuccess ||
         (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
@@ -463,13 +498,13 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (ctx) (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
-    if (b->d_in) (void)hipFree(b->d_in);
-    if (b->d_work) (void)hipFree(b->d_work);
-    if (b->d_cells) (void)hipFree(b->d_cells);
-    if (b->d_out) (void)hipFree(b->d_out);
-    if (b->d_S) (void)hipFree(b->d_S);
+    cache_give(ctx, pgm_ctx::C_IN, b->d_in, b->cap[pgm_ctx::C_IN]);
+    cache_give(ctx, pgm_ctx::C_WORK, b->d_work, b->cap[pgm_ctx::C_WORK]);
+    cache_give(ctx, pgm_ctx::C_CELLS, b->d_cells, b->cap[pgm_ctx::C_CELLS]);
+    cache_give(ctx, pgm_ctx::C_OUT, b->d_out, b->cap[pgm_ctx::C_OUT]);
+    cache_give(ctx, pgm_ctx::C_S, b->d_S, b->cap[pgm_ctx::C_S]);
     if (b->d_sync) (void)hipFree(b->d_sync);
-    if (b->h_out) (void)hipHostFree(b->h_out);
+    cache_give(ctx, pgm_ctx::C_HOST, b->h_out, b->cap[pgm_ctx::C_HOST]);
     if (b->h_flag) (void)hipHostFree(b->h_flag);
     if (b->d_items) (void)hipFree(b->d_items);
     if (b->d_trace) (void)hipFree(b->d_trace);
