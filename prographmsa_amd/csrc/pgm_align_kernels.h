@@ -288,7 +288,7 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 
 #define PGM_TB_T 32        // tile edge (rows and columns)
 #define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's (half of it for chain-only jobs)
-#define PGM_TB_MAXPAIRS 12 // most candidate pairs of a cell for which an M-state link is precomputed
+#define PGM_TB_LK 4        // an M-state link is precomputed for cells whose two nodes have at most this many predecessors each
 #define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
 struct PgmTbLds {
     float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
@@ -392,7 +392,6 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             if (y + 1 < n1 && x + 1 < n2 && (y | x) != 0u) {
                 const float4 c0 = T.cell[ci];
                 const uint32_t cy = T.p_cnt[ly], cx = T.p_cnt[TT + lx];
-                const bool oky = cy <= PGM_TB_PK, okx = cx <= PGM_TB_PK;
                 auto pick = [&](const float4 &c, uint32_t yp, uint32_t xp) -> uint16_t {   // W source resolved by equality: M, Y, X
                     uint32_t st;
                     if ((yp | xp) == 0u) st = 0u;
@@ -403,28 +402,36 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     return (uint16_t)(0x8000u | (st << 10) | ((yp - ty0) << 5) | (xp - tx0));
                 };
                 // state M: pairs (row predecessor outer, column predecessor inner)
-                // (cells with many candidate pairs get no M link: one such cell would hold up the whole tile; the walker
+                // (cells with more predecessors get no M link: one such cell would hold up the whole tile; the walker
                 // evaluates them itself, one pair per lane, if the path really visits them)
-                if (st_task == 0u && oky && okx && cy * cx <= PGM_TB_MAXPAIRS && c0.x > PGM_NEG_INF) {
+                if (st_task == 0u && cy <= PGM_TB_LK && cx <= PGM_TB_LK && cy != 0u && cx != 0u && c0.x > PGM_NEG_INF) {
                     const float S = T.S[ci];
-                    float best = INFINITY;
+                    // all operands first (the list slots beyond a node's count hold a copy of its last entry, so every read
+                    // is a valid one and nothing here branches), then the comparisons in PredIterator order
+                    uint32_t yp[PGM_TB_LK], xp[PGM_TB_LK];
+                    float yv[PGM_TB_LK], xv[PGM_TB_LK];
                     bool ok = true;
-                    uint32_t wy = 0, wx = 0, wky = 0, wkx = 0;
-                    // the comparisons only need W of each candidate cell (one dword); the winner's full cell, its
-                    // repeat markers and the state decision are read once after the search
-                    for (uint32_t ky = 0; ky < cy && ok; ++ky) {
-                        const uint32_t yp = T.p_c[ly * PGM_TB_PK + ky];
-                        const float yv = T.p_v[ly * PGM_TB_PK + ky];
-                        if (yp < ty0) { ok = false; break; }
-                        for (uint32_t kx = 0; kx < cx; ++kx) {
-                            const uint32_t xp = T.p_c[(TT + lx) * PGM_TB_PK + kx];
-                            if (xp < tx0) { ok = false; break; }
-                            const float xv = T.p_v[(TT + lx) * PGM_TB_PK + kx];
-                            const float wz = T.cell[(yp - ty0) * TT + (xp - tx0)].z;
-                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(wz, S), yv), xv)));
-                            if (best > d) { best = d; wy = yp; wx = xp; wky = ky; wkx = kx; }
-                        }
+#pragma unroll
+                    for (int k = 0; k < PGM_TB_LK; ++k) {
+                        yp[k] = T.p_c[ly * PGM_TB_PK + k]; yv[k] = T.p_v[ly * PGM_TB_PK + k];
+                        xp[k] = T.p_c[(TT + lx) * PGM_TB_PK + k]; xv[k] = T.p_v[(TT + lx) * PGM_TB_PK + k];
+                        ok = ok && ((uint32_t)k >= cy || yp[k] >= ty0) && ((uint32_t)k >= cx || xp[k] >= tx0);
                     }
+                    float wz[PGM_TB_LK][PGM_TB_LK];
+#pragma unroll
+                    for (int ky = 0; ky < PGM_TB_LK; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < PGM_TB_LK; ++kx)
+                            wz[ky][kx] = T.cell[min((yp[ky] - ty0) * TT + (xp[kx] - tx0), TT * TT - 1u)].z;
+                    float best = INFINITY;
+                    uint32_t wy = 0, wx = 0, wky = 0, wkx = 0;
+#pragma unroll
+                    for (int ky = 0; ky < PGM_TB_LK; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < PGM_TB_LK; ++kx) {
+                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(wz[ky][kx], S), yv[ky]), xv[kx])));
+                            if ((uint32_t)ky < cy && (uint32_t)kx < cx && best > d) { best = d; wy = yp[ky]; wx = xp[kx]; wky = ky; wkx = kx; }
+                        }
                     bool rep_edge = false;
                     float4 wc = c0;
                     if (ok && best < INFINITY) {
