@@ -122,7 +122,7 @@ def main():
             traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                "traffic_source": "profiles/r1_v10_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
+                "traffic_source": "profiles/r1_v11_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
                 "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4)},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
 
