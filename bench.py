@@ -117,7 +117,8 @@ def main():
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r1_v9_pmc.json")
     if headline and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get("pgm_fill_kernel<0>", {})
+        pmc_all = json.load(open(pmc_path))
+        pmc = next((v for k, v in pmc_all.items() if k.startswith("pgm_fill_kernel")), {})
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",

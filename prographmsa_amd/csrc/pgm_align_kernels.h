@@ -806,7 +806,8 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // edges, pathological graphs) fall back to reading the cell storage (HBM/L2) for all their extras.
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
 // that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
-template <int DUMMY>
+// CYCLES = true: instrumented build for tools/probe_cyc.py (cycle counters per band into map1, no traceback)
+template <bool CYCLES>
 __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace) {
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
@@ -1079,7 +1080,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             unsigned long long mcyc_wait = 0;
             float2 aux_n = *(const float2 *)(ring + xr * NQ), rep_n = make_float2(PGM_NEG_INF, PGM_NEG_INF);   // operands of step 0
             float S_n = sblk[lane];
-            const unsigned long long mc_start = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+            const unsigned long long mc_start = CYCLES ? __builtin_readcyclecounter() : 0ull;
             uint32_t ticks = 0;
             for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
                 if (t0 > 0) {
@@ -1124,10 +1125,10 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     if (need_help) {
                         // tick t: the helpers have finished the partial maxima of step t (and start on step t + 1, which
                         // needs the history up to step t - 1, complete since the previous iteration)
-                        const unsigned long long mc0 = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                        const unsigned long long mc0 = CYCLES ? __builtin_readcyclecounter() : 0ull;
                         tick();
                         ++ticks;
-                        if (DUMMY & 8) mcyc_wait += __builtin_readcyclecounter() - mc0;
+                        if (CYCLES) mcyc_wait += __builtin_readcyclecounter() - mc0;
                         const float *r1 = res1 + (t & 1u) * (2 * 64) + lane;
                         float *ra = resA + (t & 1u) * (2 * 64) + lane;
                         const float m1 = r1[0], x1 = r1[64], m2 = ra[0], y2 = ra[64];
@@ -1200,7 +1201,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if ((DUMMY & 8) && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
+            if (CYCLES && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
             if (need_help && aborted) {
                 // a hand-off timed out: tell the helpers (read after the band's last barrier) and serve the remaining ticks
                 if (lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1213,7 +1214,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             __syncthreads();   // matches the main wavefront's barrier after initialisation
             const int h = role - 1;
             const uint32_t tend = (tsteps + BL - 1) / BL * BL;   // the main wavefront always finishes its last block
-            unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+            unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = CYCLES ? __builtin_readcyclecounter() : 0ull;
             if (h == 0) {
                 // ---- helper 1: column extras, one row per lane like the main wavefront -----------------------------
                 // The column summary and the score of step t + 1 are read before the barrier of step t (they do not
@@ -1233,15 +1234,15 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
                     cj8[6] = __float_as_uint(q2.x);
                     cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
-                    if (!(DUMMY & 1) && nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
+                    if (nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
                     float *rs = res1 + (t & 1u) * (2 * 64) + lane;
                     rs[0] = Mn; rs[64] = Xn;
                     xr = (xr + 1 == R) ? 0 : xr + 1;
                     n_aux = ring[xr * NQ]; n_q1 = ring[xr * NQ + 1]; n_q2 = ring[xr * NQ + 2]; n_q3 = ring[xr * NQ + 3];
                     n_S = sblk[(((t + 1) / BL) & 1u) * (BL * 64) + ((t + 1) % BL) * 64 + lane];
-                    const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    const unsigned long long hcb = CYCLES ? __builtin_readcyclecounter() : 0ull;
                     tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    if (CYCLES) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             } else {
                 // ---- helpers 2 and 3: one ROW EXTRA (entry) per lane -----------------------------------------------
@@ -1303,7 +1304,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                 for (uint32_t t = 0; t < tend; ++t) {
                     const uint32_t t8 = t << 8;
                     const bool work = __builtin_amdgcn_ballot_w64(any) != 0;
-                    if (work && !(DUMMY & (h == 1 ? 2 : 4))) {
+                    if (work) {
                         float *ra = resA + (t & 1u) * (2 * 64);
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
@@ -1330,12 +1331,12 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                         }
                     }
                     fetch_cols(t + 1);
-                    const unsigned long long hcb = (DUMMY & 8) ? __builtin_readcyclecounter() : 0ull;
+                    const unsigned long long hcb = CYCLES ? __builtin_readcyclecounter() : 0ull;
                     tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (DUMMY & 8) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                    if (CYCLES) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
                 }
             }
-            if ((DUMMY & 8) && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
+            if (CYCLES && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
         }
         if (need_help) {
             __syncthreads();   // band finished: nobody reads the history any more
@@ -1353,7 +1354,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                 tb_go = ok ? 1 : 0;
             }
             __syncthreads();
-            if (tb_go != 0 && !(DUMMY & 8)) {
+            if (tb_go != 0 && !CYCLES) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
                 pgm_traceback_job(J, L.t, (int)threadIdx.x, 256, trace ? trace + 6 * it + 4 : nullptr);
             }

@@ -255,8 +255,8 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // One kernel does the DP fill of every band and, right after a job's last band, that job's traceback.
     const char *dbg = getenv("PGM_FILL_DBG");   // 8: cycle-counter build of the fill kernel (tools/probe_cyc.py), no traceback
     const int dbgv = dbg ? atoi(dbg) : 0;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<8>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
-    else hipLaunchKernelGGL((pgm_fill_kernel<0>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
