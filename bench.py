@@ -110,7 +110,9 @@ def main():
         dt, total_cells = float(t.item()), float(c.item())
 
     # ---- roofline of the dominant kernel (pgm_fill_kernel: DP fill + tracebacks), HIP events on the library's stream ----
-    ms_prep, ms_emis, ms_fill, _ = batch.time(5)
+    reps = sorted(batch.time(1) for _ in range(7))          # per-stage device times, median of 7 single runs
+    ms_prep, ms_emis = sorted(r[0] for r in reps)[3], sorted(r[1] for r in reps)[3]
+    ms_fill = sorted(r[2] for r in reps)[3]
     alg_bytes = 16.0 * cells            # one float4 {M,X,W,Y} store per cell; S is materialised by the emission
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
