@@ -117,7 +117,7 @@ def main():
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_v9_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v11_pmc.json")
     if headline and os.path.exists(pmc_path):
         pmc_all = json.load(open(pmc_path))
         pmc = next((v for k, v in pmc_all.items() if k.startswith("pgm_fill_kernel")), {})
