@@ -28,34 +28,55 @@ struct PgmCsArgs {
     uint32_t total;           // total residues
 };
 
+// The library (K x ncols x 21 doubles, 8.7 MB for K = 4000) is streamed through LDS in chunks of PGM_CS_KC profiles: every
+// thread of the workgroup needs every profile, and its 13 window look-ups per profile are gathers (one of 21 entries per
+// column) that LDS serves at a fraction of the L2 cost.  In LDS every column has a 22nd entry holding 0.0 for positions
+// outside the sequence (which the reference skips): pk + 0.0 == pk, so the sum is the reference's without a branch per column.
+#define PGM_CS_KC 8
 __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
+    extern __shared__ double cs_lds[];   // [KC][ncols*22] window tables, [KC][20] centre columns, [KC] priors
+    const uint32_t tab = A.ncols * 22u, gtab = A.ncols * 21u;
+    double *s_lp = cs_lds, *s_ce = cs_lds + PGM_CS_KC * tab, *s_pr = s_ce + PGM_CS_KC * 20;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= A.total) return;
-    const uint32_t s = A.pos_seq[gid];
+    const bool active = gid < A.total;
+    const uint32_t s = active ? A.pos_seq[gid] : 0u;
     const uint32_t base = A.offs[s];
     const int L = (int)(A.offs[s + 1] - base);
-    const int i = (int)(gid - base);
+    const int i = active ? (int)(gid - base) : 0;
     const int8_t *seq = A.syms + base;
     const int center = (int)A.ncols / 2;
-    // window symbols (invalid positions marked -1)
-    int win[32];
+    // window symbols; 20 = invalid residue (the library's own 21st entry), 21 = outside the sequence (0.0)
+    uint32_t woff[32];
     for (int j = -center; j <= center; ++j) {
         const int pp = i + j;
-        win[j + center] = (pp >= 0 && pp < L) ? (int)seq[pp] : -1;
+        int w = (active && pp >= 0 && pp < L) ? (int)seq[pp] : 21;
+        if (w < 0 || w > 21) w = 20;
+        woff[j + center] = (uint32_t)((j + center) * 22 + w);
     }
     double acc[20];
 #pragma unroll
     for (int a = 0; a < 20; ++a) acc[a] = 0.0;
-    for (uint32_t k = 0; k < A.K; ++k) {
-        const double *lp = A.lprofiles + (size_t)k * A.ncols * 21;
-        double pk = A.priors[k];
-        for (int c = 0; c < (int)A.ncols; ++c)
-            if (win[c] >= 0) pk = __dadd_rn(pk, lp[c * 21 + win[c]]);
-        const double e = exp(pk);
-        const double *ce = A.centre + (size_t)k * 20;
+    for (uint32_t k0 = 0; k0 < A.K; k0 += PGM_CS_KC) {
+        const uint32_t kc = min((uint32_t)PGM_CS_KC, A.K - k0);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < kc * tab; t += blockDim.x) {
+            const uint32_t e = t % 22u, cc = t / 22u;   // cc = profile-in-chunk * ncols + column
+            s_lp[t] = e < 21u ? A.lprofiles[(size_t)k0 * gtab + (size_t)cc * 21u + e] : 0.0;
+        }
+        for (uint32_t t = threadIdx.x; t < kc * 20u; t += blockDim.x) s_ce[t] = A.centre[(size_t)k0 * 20 + t];
+        if (threadIdx.x < kc) s_pr[threadIdx.x] = A.priors[k0 + threadIdx.x];
+        __syncthreads();
+        for (uint32_t kk = 0; kk < kc; ++kk) {
+            const double *lp = s_lp + kk * tab;
+            double pk = s_pr[kk];
+            for (int c = 0; c < (int)A.ncols; ++c) pk = __dadd_rn(pk, lp[woff[c]]);
+            const double e = exp(pk);
+            const double *ce = s_ce + kk * 20;
 #pragma unroll
-        for (int a = 0; a < 20; ++a) acc[a] = __dadd_rn(acc[a], __dmul_rn(ce[a], e));
+            for (int a = 0; a < 20; ++a) acc[a] = __dadd_rn(acc[a], __dmul_rn(ce[a], e));
+        }
     }
+    if (!active) return;
     // per-row finishing (CSProfile.cpp:205-222)
     const int c = seq[i];
     double sum = 0.0;
