@@ -47,46 +47,65 @@ __device__ __forceinline__ float pgm_emission_finish(float num, float ay, float 
 // graph are dealt to the slices (one thread per node), so the largest job's graphs do not serialise on one workgroup.
 //   side 0: g1f[y][k] = float(sites1(k,y));  a1[y] = sum_k g1f[y][k] * pi_f[k]
 //   side 1: t2[x][k]  = sum_j M_f(j,k) * g2f(j,x);  b2[x] = sum_k pi_f[k] g2f(k,x)
-// A node's profile column is read into registers once (DMAX = 20 for amino acids, 64 for codons); the sums keep the
-// reference's sequential order (one multiply and one add per term, no FMA).
-template <int DMAX>
-__global__ void __launch_bounds__(256) pgm_prep_kernel(const PgmJob *__restrict__ jobs) {
-    extern __shared__ float prep_lds[];  // Mf (dim*dim) then pif (dim)
+// A workgroup takes NODES consecutive nodes: their profile columns (doubles, D per node) are one contiguous run, read
+// coalesced and converted into LDS; every thread then works on its node from LDS (padded stride: conflict free), and the
+// results go back through LDS so that the stores are coalesced too.  The sums keep the reference's sequential order (one
+// multiply and one add per term, no FMA).  DMAX = 20 for amino acids (NODES = 256), 64 for codons (NODES = 64).
+template <int DMAX, int NODES>
+__global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restrict__ jobs) {
+    extern __shared__ float prep_lds[];  // Mf (dim*dim), pif (dim), nodes [NODES][dim+1]
     const PgmJob &J = jobs[blockIdx.x];
-    if (blockIdx.z * blockDim.x >= (blockIdx.y == 0 ? J.n1 : J.n2)) return;   // no nodes for this slice
-    const uint32_t D = J.dim, DP = J.dp;
-    float *Mf = prep_lds;
-    float *pif = prep_lds + D * D;
-    for (uint32_t i = threadIdx.x; i < D * D; i += blockDim.x) Mf[i] = (float)J.M[i];
-    for (uint32_t i = threadIdx.x; i < D; i += blockDim.x) pif[i] = (float)J.pi[i];
-    __syncthreads();
     const bool first = blockIdx.y == 0;
     const uint32_t n = first ? J.n1 : J.n2;
-    for (uint32_t v = blockIdx.z * blockDim.x + threadIdx.x; v < n; v += blockDim.x * gridDim.z) {
-        const double *col = (first ? J.sites1 : J.sites2) + (size_t)D * v;
-        float g[DMAX];
+    const uint32_t v0 = blockIdx.z * NODES;
+    if (v0 >= n) return;   // no nodes for this slice
+    const uint32_t D = J.dim, DP = J.dp, ST = D + 1;
+    float *Mf = prep_lds;
+    float *pif = prep_lds + D * D;
+    float *nl = pif + D;
+    const uint32_t nn = min((uint32_t)NODES, n - v0);
+    if (!first) for (uint32_t i = threadIdx.x; i < D * D; i += NODES) Mf[i] = (float)J.M[i];
+    for (uint32_t i = threadIdx.x; i < D; i += NODES) pif[i] = (float)J.pi[i];
+    const double *src = (first ? J.sites1 : J.sites2) + (size_t)D * v0;
+    float *dst = (first ? J.g1f : J.t2) + (size_t)DP * v0;
+    for (uint32_t i = threadIdx.x; i < nn * D; i += NODES) {
+        const float g = (float)src[i];
+        nl[(i / D) * ST + (i % D)] = g;
+        if (first && DP == D) dst[i] = g;                     // g1f is the converted column itself
+    }
+    __syncthreads();
+    const uint32_t v = threadIdx.x;
+    float g[DMAX];
+    float acc = 0.0f;
+    if (v < nn) {
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) g[k] = ((uint32_t)k < D) ? (float)col[k] : 0.0f;
-        float *dst = (first ? J.g1f : J.t2) + (size_t)DP * v;
-        float acc = 0.0f;
+        for (int k = 0; k < DMAX; ++k) g[k] = ((uint32_t)k < D) ? nl[v * ST + k] : 0.0f;
 #pragma unroll
         for (int k = 0; k < DMAX; ++k)
             if ((uint32_t)k < D) acc = __fadd_rn(acc, __fmul_rn(first ? g[k] : pif[k], first ? pif[k] : g[k]));
-        if (first) {
+        (first ? J.a1 : J.b2)[v0 + v] = acc;
+    }
+    if (first) {
+        if (DP != D && v < nn) {
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) if ((uint32_t)k < DP) dst[k] = g[k];
-            J.a1[v] = acc;
-        } else {
-            for (uint32_t k = 0; k < D; ++k) {
-                float t = 0.0f;
-#pragma unroll
-                for (int j = 0; j < DMAX; ++j)
-                    if ((uint32_t)j < D) t = __fadd_rn(t, __fmul_rn(Mf[j + D * k], g[j]));
-                dst[k] = t;
-            }
-            for (uint32_t k = D; k < DP; ++k) dst[k] = 0.0f;
-            J.b2[v] = acc;
+            for (int k = 0; k < DMAX; ++k) if ((uint32_t)k < DP) dst[(size_t)DP * v + k] = g[k];
         }
+        return;
+    }
+    __syncthreads();   // every thread has its column in registers: the LDS rows are reused for the results
+    if (v < nn) {
+        for (uint32_t k = 0; k < D; ++k) {
+            float t = 0.0f;
+#pragma unroll
+            for (int j = 0; j < DMAX; ++j)
+                if ((uint32_t)j < D) t = __fadd_rn(t, __fmul_rn(Mf[j + D * k], g[j]));
+            nl[v * ST + k] = t;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nn * DP; i += NODES) {
+        const uint32_t node = i / DP, k = i % DP;
+        dst[i] = k < D ? nl[node * ST + k] : 0.0f;
     }
 }
 

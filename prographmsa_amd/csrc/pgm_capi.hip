@@ -240,10 +240,13 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipStream_t s = ctx->stream;
     hipError_t e;
     if (timed && (e = hipEventRecord(b->ev[0], s)) != hipSuccess) return e;
-    const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim) * sizeof(float);
-    const dim3 pg(b->njobs, 2, (b->maxn + 255) / 256);
-    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_prep_kernel<20>), pg, dim3(256), prep_lds, s, b->d_jobs);
-    else hipLaunchKernelGGL((pgm_prep_kernel<64>), pg, dim3(256), prep_lds, s, b->d_jobs);
+    if (b->maxdim <= 20) {
+        const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim + 256 * ((size_t)b->maxdim + 1)) * sizeof(float);
+        hipLaunchKernelGGL((pgm_prep_kernel<20, 256>), dim3(b->njobs, 2, (b->maxn + 255) / 256), dim3(256), prep_lds, s, b->d_jobs);
+    } else {
+        const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim + 64 * ((size_t)b->maxdim + 1)) * sizeof(float);
+        hipLaunchKernelGGL((pgm_prep_kernel<64, 64>), dim3(b->njobs, 2, (b->maxn + 63) / 64), dim3(64), prep_lds, s, b->d_jobs);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
     const dim3 eg((b->maxnblk + PGM_EM_TB - 1) / PGM_EM_TB, (b->maxnb + 3) / 4, b->njobs);
