@@ -1059,10 +1059,12 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                 }
             };
             int seen = has_prev ? 0 : 0x7fffffff, pend = 0;
+            unsigned long long wait_ticks = 0;   // timeline only: time spent waiting for band b-1
             auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
                 if (seen != 0x7fffffff && !aborted) {
                     const int need = (int)min(steps_needed, tsteps);
                     uint32_t spins = 0;
+                    const unsigned long long w0 = (trace && seen < need) ? __builtin_amdgcn_s_memrealtime() : 0ull;
                     while (seen < need) {
                         seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (seen >= need) break;
@@ -1073,6 +1075,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                             break;
                         }
                     }
+                    if (w0) wait_ticks += __builtin_amdgcn_s_memrealtime() - w0;
                 }
             };
             // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
@@ -1228,6 +1231,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (trace && threadIdx.x == 0) trace[6 * it] |= wait_ticks << 16;   // (wavefront 0 of the worker; worker id in the low 16 bits)
         } else if (need_help) {
             // =========================================== helper wavefronts ==========================================
             __syncthreads();   // matches the main wavefront's barrier after initialisation

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <queue>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -373,38 +374,73 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) {
         return (uint64_t)b->jobs[x].n1 * b->jobs[x].n2 > (uint64_t)b->jobs[y].n1 * b->jobs[y].n2;
     });
-    // ---- fill work list: every band of every job, longest remaining path first.  The remaining path of band b is
-    // the time until its job is complete once the band can start: the (nb-1-b) band-to-band lags still ahead plus one
-    // full sweep, at the job's step time (chain-only jobs: the main wavefront alone, ~0.38 us; merged graphs: lock-step
-    // with the helper wavefronts, ~0.65 us).  Within a job the order is band 0, 1, 2, ... as the kernel requires.
+    // ---- fill work list.  An item is a band (merged graphs) or a group of four bands (chain-only jobs); item k of a job
+    // can start once item k-1 has been running for the band-to-band lag, and the workers take items in list order.  The
+    // order is the result of simulating the persistent workers on the host with estimated times: whenever a worker is
+    // free it takes, among the items that are READY by then, the one with the longest remaining path (the time until its
+    // job is complete: the lags still ahead, one full sweep, the traceback).  Within a job the items keep ascending
+    // order, as the kernel requires; taking only ready items keeps workers from idling in front of a predecessor band.
+    // Step times: ~0.38 us for a chain-only band (main wavefront alone), ~0.7 us in lock-step with the helpers.
     std::vector<PgmItem> items;
+    uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
+    // persistent workers: 2 workgroups of 4 wavefronts per CU.  A third would fit, but co-resident workers slow each other
+    // down and the batch's makespan is its longest job's critical path: measured on the 256 x 1000 batch 7.3 / 6.6 / 7.0 ms
+    // at 1.5 / 2 / 2.5 per CU (tools/probe_trace.py)
+    if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
     if (njobs) {
-        struct Key { double rem; uint32_t job, band, count; };
-        std::vector<Key> keys;
-        const double lag = PGM_ROWS + 4.0 * PGM_BLOCK;
+        struct Item { double rem, dur, gap; uint32_t job, band, count; };
+        std::vector<std::vector<Item>> per_job(njobs);
+        const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
+        size_t total = 0;
+        double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
-            const double tau = J.has_extras ? 0.65 : 0.38;      // us per step
-            const double tb = 0.8 * (double)(J.n1 + J.n2);       // the traceback follows the last band (us)
+            const double tau = J.has_extras ? 0.7 : 0.38;        // us per step
+            const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             const uint32_t group = J.has_extras ? 1u : 4u;       // chain-only jobs: four bands per item, one per wavefront
-            for (uint32_t band = 0; band < J.nb; band += group)
-                keys.push_back({tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb, i, band, std::min(group, J.nb - band)});
+            for (uint32_t band = 0; band < J.nb; band += group) {
+                const uint32_t cnt = std::min(group, J.nb - band);
+                const bool last = band + cnt == J.nb;
+                Item it;
+                it.rem = tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb;
+                it.dur = tau * ((double)(cnt - 1) * lag + J.tsteps) + (last ? tb : 0.0);
+                it.gap = tau * (double)cnt * lag;                 // the next item may start this long after this one
+                it.job = i; it.band = band; it.count = cnt;
+                per_job[i].push_back(it);
+                rmax = std::max(rmax, it.rem);
+            }
+            total += per_job[i].size();
         }
-        std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) { return x.rem > y.rem; });
-        items.reserve(keys.size());
-        // wave priority (s_setprio) of a band: the longest paths of the batch win the issue arbitration on their SIMDs
-        const double rmax = keys.empty() ? 1.0 : keys.front().rem;
-        for (const Key &k : keys) items.push_back(PgmItem{k.job, k.band, k.rem > 0.6 * rmax ? 3u : (k.rem > 0.35 * rmax ? 2u : (k.rem > 0.2 * rmax ? 1u : 0u)), k.count});
+        // event simulation: free workers (min-heap of times), ready items (max-heap of remaining paths), pending successors
+        typedef std::pair<double, uint32_t> TE;   // (time, job)
+        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+        for (uint32_t w = 0; w < std::max(1u, capacity); ++w) free_at.push(0.0);
+        std::priority_queue<TE> ready;                                               // (rem, job): next item of that job
+        std::priority_queue<TE, std::vector<TE>, std::greater<TE>> pending;         // (ready time, job)
+        std::vector<uint32_t> next(njobs, 0);
+        for (uint32_t i = 0; i < njobs; ++i) if (!per_job[i].empty()) ready.push({per_job[i][0].rem, i});
+        items.reserve(total);
+        double now = 0.0;
+        while (items.size() < total) {
+            now = std::max(now, free_at.top());
+            while (!pending.empty() && pending.top().first <= now) {
+                const uint32_t j = pending.top().second; pending.pop();
+                ready.push({per_job[j][next[j]].rem, j});
+            }
+            if (ready.empty()) { now = pending.top().first; continue; }              // every free worker would have to wait
+            const uint32_t j = ready.top().second; ready.pop();
+            const Item &it = per_job[j][next[j]];
+            // wave priority (s_setprio): the longest paths of the batch win the issue arbitration on their SIMDs
+            items.push_back(PgmItem{it.job, it.band, it.rem > 0.6 * rmax ? 3u : (it.rem > 0.35 * rmax ? 2u : (it.rem > 0.2 * rmax ? 1u : 0u)), it.count});
+            free_at.pop();
+            free_at.push(now + it.dur);
+            // the longest paths of the batch are not held back: their next band gets a worker at once (it spins until the
+            // predecessor is far enough, but then follows it without any queueing delay)
+            if (++next[j] < per_job[j].size()) pending.push({per_job[j][next[j]].rem > 0.7 * rmax ? now : now + it.gap, j});
+        }
     }
     b->nitems = (uint32_t)items.size();
-    {
-        // persistent workers: 2 workgroups of 4 wavefronts per CU.  A third would fit, but co-resident workers slow each
-        // other down (LDS traffic) and the batch's makespan is its longest job's critical path: measured on the 256 x 1000
-        // batch 7.3 / 6.6 / 7.0 ms at 1.5 / 2 / 2.5 per CU (tools/probe_trace.py)
-        uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
-        if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
-        b->nworkers = std::max(1u, std::min(capacity, b->nitems));
-    }
+    b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     if ((e = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST])) != hipSuccess ||
         (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);

@@ -24,7 +24,10 @@ tr = raw[:, :4].astype(np.float64)
 t0 = tr[:, 1].min()
 start, bend, tend = (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0, np.where(tr[:, 3] > 0, (tr[:, 3] - t0) / 100.0, 0)   # us
 end = np.maximum(bend, tend)
+wait_us = (raw[:, 0] >> np.uint64(16)).astype(np.float64) / 100.0
+tr[:, 0] = (raw[:, 0] & np.uint64(0xffff)).astype(np.float64)
 print("items %d, workers %d, makespan %.0f us" % (n, len(set(tr[:, 0])), end.max()))
+print("time spent waiting for the previous band (wavefront 0 of each item): %.0f us-worker" % wait_us.sum())
 busy = (end - start).sum()
 print("sum of item times %.0f us-worker = %.1f%% of workers x makespan" % (busy, 100 * busy / (len(set(tr[:, 0])) * end.max())))
 tb = np.where(tend > 0, tend - bend, 0)
