@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <thread>
+#include <atomic>
 #include <queue>
 #include <cstdlib>
 #include <cstring>
@@ -32,9 +34,9 @@ struct pgm_ctx {
     hipStream_t stream = nullptr;
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
     // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
-    enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_SLOTS };
-    void *cache_ptr[C_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0};
+    enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SLOTS };   // C_HOST, C_HIN: pinned host memory
+    void *cache_ptr[C_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0, 0};
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0;
     // context-profile library resident in HBM
@@ -43,15 +45,17 @@ struct pgm_ctx {
 };
 
 // ---- arena: one host staging buffer mirrored by one device allocation ------------------------
-struct Arena {
-    std::vector<uint8_t> host;
+struct Arena {   // bump allocator over a slice [off, end) of an external host buffer; offsets are relative to `base`
+    uint8_t *base = nullptr;
+    size_t off = 0, end = 0;
+    bool overflow = false;
     size_t put(const void *src, size_t bytes, size_t align = 16) {
-        size_t off = (host.size() + align - 1) / align * align;
-        host.resize(off + bytes);
-        if (src && bytes) memcpy(host.data() + off, src, bytes);
-        return off;
+        const size_t o = (off + align - 1) / align * align;
+        if (o + bytes > end) { overflow = true; return 0; }
+        off = o + bytes;
+        if (src && bytes) memcpy(base + o, src, bytes);
+        return o;
     }
-    size_t reserve(size_t bytes, size_t align = 16) { return put(nullptr, bytes, align); }
 };
 struct DevLayout {  // sizes of device-only regions
     size_t bytes = 0;
@@ -74,6 +78,7 @@ struct pgm_align_batch {
     uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // real sizes of the buffers taken from the context's cache
     uint8_t *h_out = nullptr;          // pinned staging buffer of the result block (one D2H copy per fetch)
+    uint8_t *h_in = nullptr;           // pinned staging buffer of the flattened inputs (one H2D copy per create)
     int *h_flag = nullptr;
     uint8_t *d_S = nullptr;           // emission scores in fill order
     int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
@@ -121,7 +126,7 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
-        if (ctx->cache_ptr[k]) { if (k == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[k]); else (void)hipFree(ctx->cache_ptr[k]); }
+        if (ctx->cache_ptr[k]) { if ((k == pgm_ctx::C_HOST || k == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[k]); else (void)hipFree(ctx->cache_ptr[k]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -221,19 +226,19 @@ static hipError_t cache_take(pgm_ctx *ctx, int slot, size_t bytes, void **out, s
         return hipSuccess;
     }
     if (ctx->cache_ptr[slot]) {   // too small: replace
-        if (slot == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]);
+        if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]);
         ctx->cache_ptr[slot] = nullptr; ctx->cache_bytes[slot] = 0;
     }
     *got = bytes;
-    return slot == pgm_ctx::C_HOST ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    return (slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN) ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
 }
 static void cache_give(pgm_ctx *ctx, int slot, void *p, size_t bytes) {
     if (!p) return;
     if (ctx && (!ctx->cache_ptr[slot] || ctx->cache_bytes[slot] < bytes)) {
-        if (ctx->cache_ptr[slot]) { if (slot == pgm_ctx::C_HOST) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]); }
+        if (ctx->cache_ptr[slot]) { if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]); }
         ctx->cache_ptr[slot] = p; ctx->cache_bytes[slot] = bytes;
     } else {
-        if (slot == pgm_ctx::C_HOST) (void)hipHostFree(p); else (void)hipFree(p);
+        if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(p); else (void)hipFree(p);
     }
 }
 
@@ -278,16 +283,25 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     pgm_align_batch *b = new pgm_align_batch;
     b->njobs = njobs;
     b->jobs.resize(njobs);
-    Arena A;
     DevLayout W, C, O, SL;
     size_t sync_ints = 4;   // [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
     std::vector<size_t> prog_off(njobs), s_off(njobs);
     struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
+    // pass 1 (serial, O(jobs)): sizes, device layouts, and an upper bound of each job's flattened input
+    auto side_bound = [](const pgm_graph *g) -> size_t {
+        const size_t n = g->n;
+        size_t E = (size_t)std::max(0, g->e_rowptr ? g->e_rowptr[n] : 0);
+        if (g->r_rowptr) E += (size_t)std::max(0, g->r_rowptr[n]);
+        E = std::max<size_t>(E, 1);
+        return n * g->dim * 8 + n * sizeof(PgmNodeInfo) + 2 * (n + 1) * 4 + E * 20 + 16 * 16;
+    };
+    std::vector<size_t> in_base(njobs + 1, 0);
     for (uint32_t i = 0; i < njobs; ++i) {
         const pgm_graph *a = g1[i], *c = g2[i];
-        if (!a || !c || !model[i] || a->dim != c->dim || a->dim == 0 || a->dim > 64 || a->n < 2 || c->n < 2 || !model[i]->M || !model[i]->pi) {
+        if (!a || !c || !model[i] || a->dim != c->dim || a->dim == 0 || a->dim > 64 || a->n < 2 || c->n < 2 || !model[i]->M || !model[i]->pi ||
+            !a->sites || !a->e_rowptr || !c->sites || !c->e_rowptr) {
             delete b;
             return fail(PGM_ERR_INVALID, "invalid job " + std::to_string(i));
         }
@@ -307,13 +321,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         b->maxnb = std::max(b->maxnb, J.nb);
         b->cells += (uint64_t)(a->n - 2) * (c->n - 2);
         Off &o = off[i];
-        if (flatten_side(a, J.sc, A, o.s1) != PGM_OK || flatten_side(c, J.sc, A, o.s2) != PGM_OK) {
-            delete b;
-            return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
-        }
-        J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
-        o.M = A.put(model[i]->M, sizeof(double) * a->dim * a->dim);
-        o.pi = A.put(model[i]->pi, sizeof(double) * a->dim);
+        in_base[i + 1] = in_base[i] + side_bound(a) + side_bound(c) + ((size_t)a->dim * a->dim + a->dim) * 8 + 64;
         o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
         o.a1 = W.take(sizeof(float) * J.n1);
         o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
@@ -329,13 +337,47 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         sync_ints += (J.nb + 3) / 4 * 4;
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
-    b->in_bytes = std::max<size_t>(A.host.size(), 16);
+    // pass 2 (host threads): flatten every job straight into a pinned staging buffer (kept by the context)
+    b->in_bytes = std::max<size_t>(in_base[njobs], 16);
+    hipError_t e;
+    if ((e = cache_take(ctx, pgm_ctx::C_HIN, b->in_bytes, (void **)&b->h_in, &b->cap[pgm_ctx::C_HIN])) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    {
+        std::atomic<int> bad(-1);
+        std::atomic<uint32_t> next_job(0);
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t i = next_job.fetch_add(1);
+                if (i >= njobs) break;
+                Arena A;
+                A.base = b->h_in; A.off = in_base[i]; A.end = in_base[i + 1];
+                PgmJob &J = b->jobs[i];
+                Off &o = off[i];
+                if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); continue; }
+                J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
+                o.M = A.put(model[i]->M, sizeof(double) * J.dim * J.dim);
+                o.pi = A.put(model[i]->pi, sizeof(double) * J.dim);
+                if (A.overflow) bad.store((int)i);
+            }
+        };
+        const unsigned nthr = std::max(1u, std::min(8u, std::min(njobs, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (bad.load() >= 0) {
+            const int i = bad.load();
+            pgm_align_batch_destroy(ctx, b);
+            return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
+        }
+    }
     b->work_bytes = std::max<size_t>(W.bytes, 16);
     b->cell_bytes = std::max<size_t>(C.bytes, 16);
     b->out_bytes = std::max<size_t>(O.bytes, 16);
     b->s_bytes = std::max<size_t>(SL.bytes, 16);
     b->sync_ints = sync_ints;
-    hipError_t e;
     if ((e = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN])) != hipSuccess ||
         (e = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK])) != hipSuccess ||
         (e = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS])) != hipSuccess ||
@@ -451,7 +493,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
-    if ((e = hipMemcpyAsync(b->d_in, A.host.data(), A.host.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+    if ((e = hipMemcpyAsync(b->d_in, b->h_in, b->in_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
@@ -544,6 +586,7 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     cache_give(ctx, pgm_ctx::C_S, b->d_S, b->cap[pgm_ctx::C_S]);
     if (b->d_sync) (void)hipFree(b->d_sync);
     cache_give(ctx, pgm_ctx::C_HOST, b->h_out, b->cap[pgm_ctx::C_HOST]);
+    cache_give(ctx, pgm_ctx::C_HIN, b->h_in, b->cap[pgm_ctx::C_HIN]);
     if (b->h_flag) (void)hipHostFree(b->h_flag);
     if (b->d_items) (void)hipFree(b->d_items);
     if (b->d_trace) (void)hipFree(b->d_trace);
