@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                     const int W_up = pgm_dpp_shr1_i(W_o, __builtin_amdgcn_readlane(pf_w, i));
                     const int Y_up = pgm_dpp_shr1_i(Y_o, __builtin_amdgcn_readlane(pf_y, i));
                     const int sidx = sy + sd * sx;  // scoring_matrix(s2(y), s1(x))
-                    const int dc = W_diag + nw_score[active ? sidx : 0];
+                    const int dc = W_diag + nw_score[sidx];   // (sx, sy are valid symbols in every lane, also the idle ones)
                     const int Xv = max(X_left + ge, W_left + go);
                     const int Yv = max(Y_up + ge, W_up + go);
                     const int xy = max(Xv, Yv);
@@ -117,8 +117,10 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                         if (lane == 63 && b + 1 < nb) brow[x] = make_int2(Wv, Yv);
                     }
                     if (x >= 1) W_diag = W_up;  // keep W(y-1,0) until the lane reaches column 1
-                    W_o = active ? Wv : MINF;
-                    Y_o = active ? Yv : MINF;
+                    // a lane's outputs are only consumed by the lane below one step later, which is active only if this one
+                    // was: idle lanes may pass on whatever they computed
+                    W_o = Wv;
+                    Y_o = Yv;
                     sx_o = sx;
                 }
             }
