@@ -428,7 +428,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // persistent workers: 2 workgroups of 4 wavefronts per CU.  A third would fit, but co-resident workers slow each other
     // down and the batch's makespan is its longest job's critical path: measured on the 256 x 1000 batch 7.3 / 6.6 / 7.0 ms
     // at 1.5 / 2 / 2.5 per CU (tools/probe_trace.py)
-    if (const char *env_c = getenv("PGM_FILL_WORKERS")) capacity = std::min<uint32_t>(capacity, (uint32_t)std::max(1, atoi(env_c)));   // experiments only
+    if (const char *env_c = getenv("PGM_FILL_WORKERS"))   // experiments only (at most 3 per CU fit)
+        capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount * 3u, (uint32_t)std::max(1, atoi(env_c)));
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
         std::vector<std::vector<Item>> per_job(njobs);
