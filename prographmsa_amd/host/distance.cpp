@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <fstream>
+#include <thread>
 
 namespace pgm {
 
@@ -145,14 +146,28 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
     be.nw_pairs_batch(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), np, pi.data(),
                       pj.data(), counts.data(), gaps.data());
     be.seconds_nw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::vector<int32_t> c((size_t)D * D);
-    for (uint32_t p = 0; p < np; ++p) {
-        std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
-        double L1 = offs[pi[p] + 1] - offs[pi[p]], L2 = offs[pj[p] + 1] - offs[pj[p]];
-        distvar_t dv = computeDistance(c, gaps[p], (L1 + L2) / 2.0);
-        distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
-        distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
-    }
+    // ML distance per pair (Newton on d, each step a 20x20 P(d)): independent per pair, so the pairs are dealt to host
+    // threads; every pair's arithmetic is the single-threaded one, the matrix entries written are disjoint
+    auto t1 = std::chrono::steady_clock::now();
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
+    nt = std::max(1u, std::min(nt, 16u));
+    nt = (unsigned)std::min<uint32_t>(nt, std::max(1u, np));
+    auto work = [&](unsigned t) {
+        std::vector<int32_t> c((size_t)D * D);
+        for (uint32_t p = t; p < np; p += nt) {
+            std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
+            double L1 = offs[pi[p] + 1] - offs[pi[p]], L2 = offs[pj[p] + 1] - offs[pj[p]];
+            distvar_t dv = computeDistance(c, gaps[p], (L1 + L2) / 2.0);
+            distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
+            distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     return distances;
 }
 

@@ -214,7 +214,7 @@ struct Backend {
                                         const uint64_t *out_offs) = 0;
     uint64_t cells_aligned = 0;   // Σ (n1-2)(n2-2)
     uint64_t cells_nw = 0;        // Σ L1*L2
-    double seconds_align = 0, seconds_nw = 0;
+    double seconds_align = 0, seconds_nw = 0, seconds_mldist = 0;
 };
 Backend &default_backend();            // defined by exactly one backend_*.cpp linked into the program
 void set_job_dump(const std::string &path);  // if set, every alignGraphs job is appended to this file
