@@ -8,6 +8,8 @@
 #include "pgm_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <thread>
@@ -139,6 +141,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             if (nodes[i].height == h) level.push_back((int)i);
         const size_t L = level.size();
         std::vector<Pending> pend(L);
+        const auto tp0 = std::chrono::steady_clock::now();
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             const ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
@@ -153,10 +156,12 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             p.cg1.reset(new CleanedGraph(r1.graph));
             p.cg2.reset(new CleanedGraph(r2.graph));
         });
+        const auto tp1 = std::chrono::steady_clock::now();
         std::vector<const Graph *> g1(L), g2(L);
         std::vector<const Model *> mm(L);
         for (size_t k = 0; k < L; ++k) { g1[k] = pend[k].cg1.get(); g2[k] = pend[k].cg2.get(); mm[k] = &pend[k].model; }
         std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm);
+        const auto tp2 = std::chrono::steady_clock::now();
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
@@ -178,6 +183,11 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             p.cg1.reset();
             p.cg2.reset();
         });
+        const auto tp3 = std::chrono::steady_clock::now();
+        if (getenv("PGM_HOST_PROFILE"))
+            fprintf(stderr, "level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n", h, L,
+                    std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
+                    std::chrono::duration<double, std::milli>(tp3 - tp2).count());
     }
     return std::move(nodes[root].res);
 }
