@@ -96,6 +96,14 @@ def main():
     w("cd2.fa", gen.fasta(gen.gen_codon(16, 150, 22, sub=0.05, indel=0.008)))
     w("cd2.tree", run(["--codon", "-T", "-i", "0", "cd2.fa"]))
     w("cd2.out.fa", run(["--codon", "--fasta", "-t", "cd2.tree", "cd2.fa"]))
+    # larger codon families, md5 only (the FASTA is regenerated by tests/gen.py): 40 x 330 and 64 x 500 codons
+    for name, fam in (("cd3", gen.gen_codon(40, 330, 23, sub=0.05, indel=0.008)), ("cd4", gen.gen_codon(64, 500, 24, sub=0.04, indel=0.005))):
+        fa = gen.fasta(fam)
+        w(name + ".fa.tmp", fa)
+        w(name + ".tree", run(["--codon", "-T", "-i", "0", name + ".fa.tmp"]))
+        md5[name + ".fa"] = hashlib.md5(fa.encode()).hexdigest()
+        md5[name + ".out.fa"] = hashlib.md5(run(["--codon", "--fasta", "-t", name + ".tree", name + ".fa.tmp"]).encode()).hexdigest()
+        os.remove(name + ".fa.tmp")
     # codon alignPair + ML distance, 2 sequences each (a 6-taxon BioNJ tree would end in the exact 4-taxon NJ tie again)
     cnw = {}
     for seed in range(300, 306):

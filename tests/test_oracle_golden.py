@@ -89,6 +89,17 @@ def test_codon_fasta_identical_to_reference(oracle_build, case):
     assert out == gold(case + ".out.fa")
 
 
+@pytest.mark.parametrize("case,n,L,seed,sub,indel", [("cd3", 40, 330, 23, 0.05, 0.008), ("cd4", 64, 500, 24, 0.04, 0.005)])
+def test_codon_family_md5(oracle_build, tmp_path, case, n, L, seed, sub, indel):
+    """Larger codon families: md5 of the reference's FASTA (pins the oracle's 61-state path at scale)."""
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    fa = gen.fasta(gen.gen_codon(n, L, seed, sub=sub, indel=indel))
+    assert hashlib.md5(fa.encode()).hexdigest() == md5[case + ".fa"]
+    (tmp_path / "cd.fa").write_text(fa)
+    out = run_oracle(oracle_build, ["--codon", "--fasta", "-t", os.path.join(GOLD, case + ".tree"), str(tmp_path / "cd.fa")])
+    assert hashlib.md5(out.encode()).hexdigest() == md5[case + ".out.fa"]
+
+
 def test_codon_nw_distance_pairs(oracle_build, tmp_path):
     nw = json.load(open(os.path.join(GOLD, "nw_pairs_codon.json")))
     for seed, p in nw.items():
