@@ -113,6 +113,23 @@ static void ls_log_add(float *data, float add, size_t len) {
 /* Summation order: Eigen's order is not visible in the source; SURVEY §7 established       */
 /* empirically against the binary that each output element is accumulated over k ascending */
 /* from zero, multiply then add, with T = M^T g2s formed first.                             */
+/* The two denominators g1s^T*pi and pi^T*g2s (GraphAlign.h:153) are matrix-vector products: Eigen's SSE kernel
+ * (GeneralMatrixVector.h, row-major lhs) accumulates four lane sums over the packets of four floats, adds them
+ * horizontally as (a0+a2)+(a1+a3) (SSE predux) and then adds the scalar tail (DIM = 61: element 60).  The numerators are
+ * matrix-matrix products, whose kernel accumulates sequentially over k (precompute_scores below).  Pinned by the
+ * fixture c2.m.out.fa (tests/golden/md5.json): with sequential denominators one cell of one alignment of that family
+ * is 1 ulp off and a gap moves by one column; cd1..cd4 pin the 61-state tail handling. */
+static float packet_dot(const float *u, const float *v, uint32_t D) {
+    float l[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t aligned = D / 4 * 4;
+    for (uint32_t k = 0; k < aligned; k += 4)
+        for (int q = 0; q < 4; ++q) { float p = u[k + q] * v[k + q]; l[q] = l[q] + p; }
+    float t02 = l[0] + l[2], t13 = l[1] + l[3];
+    float acc = 0.0f + (t02 + t13);
+    for (uint32_t k = aligned; k < D; ++k) { float p = u[k] * v[k]; acc = acc + p; }
+    return acc;
+}
+
 static void precompute_scores(const pgm_graph *g1, const pgm_graph *g2, const pgm_model *model,
                               float match_init, float *S /* n1 x n2 col-major */) {
     const uint32_t D = g1->dim, n1 = g1->n, n2 = g2->n;
@@ -137,20 +154,10 @@ static void precompute_scores(const pgm_graph *g1, const pgm_graph *g2, const pg
             }
             T[k + D * x] = acc;
         }
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < D; ++k) {
-            float p = pif[k] * g2s[k + D * x];
-            acc = acc + p;
-        }
-        b[x] = acc;
+        b[x] = packet_dot(pif, g2s + (size_t)D * x, D);
     }
     for (uint32_t y = 0; y < n1; ++y) {
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < D; ++k) {
-            float p = g1s[k + D * y] * pif[k];
-            acc = acc + p;
-        }
-        a[y] = acc;
+        a[y] = packet_dot(g1s + (size_t)D * y, pif, D);
     }
     for (uint32_t x = 0; x < n2; ++x) {
         for (uint32_t y = 0; y < n1; ++y) {

@@ -80,9 +80,23 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
     if (v < nn) {
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) g[k] = ((uint32_t)k < D) ? nl[v * ST + k] : 0.0f;
+        // denominators g1^T pi / pi^T g2: the reference's matrix-vector kernel (Eigen SSE) sums four lanes over the packets
+        // of four, adds them as (l0 + l2) + (l1 + l3), then the scalar tail (61 states: element 60) -- not sequentially
+        float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
+        const uint32_t aligned = D / 4u * 4u;
+#pragma unroll
+        for (int k = 0; k + 3 < DMAX; k += 4) {
+            if ((uint32_t)k < aligned) {
+                l0 = __fadd_rn(l0, __fmul_rn(g[k], pif[k]));
+                l1 = __fadd_rn(l1, __fmul_rn(g[k + 1], pif[k + 1]));
+                l2 = __fadd_rn(l2, __fmul_rn(g[k + 2], pif[k + 2]));
+                l3 = __fadd_rn(l3, __fmul_rn(g[k + 3], pif[k + 3]));
+            }
+        }
+        acc = __fadd_rn(0.0f, __fadd_rn(__fadd_rn(l0, l2), __fadd_rn(l1, l3)));
 #pragma unroll
         for (int k = 0; k < DMAX; ++k)
-            if ((uint32_t)k < D) acc = __fadd_rn(acc, __fmul_rn(first ? g[k] : pif[k], first ? pif[k] : g[k]));
+            if ((uint32_t)k >= aligned && (uint32_t)k < D) acc = __fadd_rn(acc, __fmul_rn(g[k], pif[k]));
         (first ? J.a1 : J.b2)[v0 + v] = acc;
     }
     if (first) {

@@ -96,6 +96,9 @@ def main():
     w("cd2.fa", gen.fasta(gen.gen_codon(16, 150, 22, sub=0.05, indel=0.008)))
     w("cd2.tree", run(["--codon", "-T", "-i", "0", "cd2.fa"]))
     w("cd2.out.fa", run(["--codon", "--fasta", "-t", "cd2.tree", "cd2.fa"]))
+    # the 64 x 400 family with context-specific profiles and with --mldist, md5 only
+    md5["c2.cs.out.fa"] = hashlib.md5(run(["--fasta", "--tree", "c2.tree", "--cs_profile", "K50.lib", "c2.fa"]).encode()).hexdigest()
+    md5["c2.m.out.fa"] = hashlib.md5(run(["--fasta", "-m", "--tree", "c2.tree", "c2.fa"]).encode()).hexdigest()
     # larger codon families, md5 only (the FASTA is regenerated by tests/gen.py): 40 x 330 and 64 x 500 codons
     for name, fam in (("cd3", gen.gen_codon(40, 330, 23, sub=0.05, indel=0.008)), ("cd4", gen.gen_codon(64, 500, 24, sub=0.04, indel=0.005))):
         fa = gen.fasta(fam)

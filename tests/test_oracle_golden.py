@@ -89,6 +89,13 @@ def test_codon_fasta_identical_to_reference(oracle_build, case):
     assert out == gold(case + ".out.fa")
 
 
+@pytest.mark.parametrize("name,flags", [("c2.cs.out.fa", ["--cs_profile", os.path.join(GOLD, "K50.lib")]), ("c2.m.out.fa", ["-m"])])
+def test_c2_variants_md5(oracle_build, name, flags):
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    out = run_oracle(oracle_build, ["--fasta"] + flags + ["--tree", os.path.join(GOLD, "c2.tree"), os.path.join(GOLD, "c2.fa")])
+    assert hashlib.md5(out.encode()).hexdigest() == md5[name]
+
+
 @pytest.mark.parametrize("case,n,L,seed,sub,indel", [("cd3", 40, 330, 23, 0.05, 0.008), ("cd4", 64, 500, 24, 0.04, 0.005)])
 def test_codon_family_md5(oracle_build, tmp_path, case, n, L, seed, sub, indel):
     """Larger codon families: md5 of the reference's FASTA (pins the oracle's 61-state path at scale)."""
