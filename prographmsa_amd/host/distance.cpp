@@ -179,6 +179,35 @@ static double support(double d) {
     return s;
 }
 
+// Column sum in the association Eigen's vectorised reduction uses for `distances.colwise().sum()` (TreeNJ.cpp:157):
+// SSE2 packets of two doubles starting at the first 16-byte aligned element of the column (the matrix is column-major and
+// 16-byte aligned, so column j starts aligned iff j*dim is even), two packet accumulators over alternating packets, the
+// accumulators added, an odd last packet added, the two lanes added, then the unaligned head and the tail element.
+// It matters: when four clusters are left the criterion has the exact tie Q(0,1) = Q(2,3), and the last bit of these sums
+// decides which pair is joined, i.e. where the guide tree is rooted (tests/golden: c1.nw_ml.tree, t9.nw_p.tree, t13.nw_p.tree).
+static double eigen_column_sum(DistanceMatrix &dist, int j) {
+    const int n = dist.dim;
+    auto at = [&](int i) { return dist.D(i, j); };   // the matrix is symmetric
+    const int start = std::min<int>(((size_t)j * n) & 1, n);
+    const int end2 = start + ((n - start) / 4) * 4, end = start + ((n - start) / 2) * 2;
+    if (end == start) {
+        double res = at(0);
+        for (int k = 1; k < n; ++k) res += at(k);
+        return res;
+    }
+    double a0 = at(start), a1 = at(start + 1);
+    if (end - start > 2) {
+        double b0 = at(start + 2), b1 = at(start + 3);
+        for (int k = start + 4; k < end2; k += 4) { a0 += at(k); a1 += at(k + 1); b0 += at(k + 2); b1 += at(k + 3); }
+        a0 += b0; a1 += b1;
+        if (end > end2) { a0 += at(end2); a1 += at(end2 + 1); }
+    }
+    double res = a0 + a1;
+    for (int k = 0; k < start; ++k) res += at(k);
+    for (int k = end; k < n; ++k) res += at(k);
+    return res;
+}
+
 PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
     const double MIN_DIST = 1e-4, MIN_VAR = 1e-5;
     std::vector<PhyTree *> subtrees;
@@ -188,11 +217,7 @@ PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
         for (double &v : dist.variances) v = std::max(v, MIN_VAR);
         for (int i = 0; i < dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
         std::vector<double> sums(dim, 0.0);  // colwise sums
-        for (int j = 0; j < dim; ++j) {
-            double s = 0;
-            for (int i = 0; i < dim; ++i) s += dist.D(i, j);
-            sums[j] = s;
-        }
+        for (int j = 0; j < dim; ++j) sums[j] = eigen_column_sum(dist, j);
         // Q = 0.5 d - 0.5/(dim-2) (S + S^T); minCoeff scans column-major (row index fastest) and keeps the first minimum
         int index1 = 0, index2 = 0;
         double min = INFINITY;

@@ -17,6 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import gen  # noqa: E402
 
+ONLY = None
+if "--only" in sys.argv:   # regenerate one section only (currently: nw_trees)
+    i = sys.argv.index("--only")
+    ONLY = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 BIN = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/bin/ProGraphMSA_64"
 
 
@@ -29,8 +34,29 @@ def w(name, text):
         f.write(text)
 
 
+NW_TREE_CASES = [  # (taxa, length, seed, substitution rate, indel rate): odd and even sizes, see nw_trees()
+    (5, 250, 585126, 0.05, 0.005), (6, 250, 81768, 0.05, 0.005), (7, 120, 59769, 0.1, 0.005), (9, 60, 815905, 0.2, 0.005),
+    (9, 250, 4816, 0.1, 0.02), (11, 120, 348741, 0.05, 0.02), (13, 120, 133400, 0.2, 0.02), (16, 120, 653397, 0.2, 0.005),
+    (16, 60, 944662, 0.2, 0.005), (16, 250, 545337, 0.1, 0.02), (21, 120, 295589, 0.05, 0.02), (30, 60, 7, 0.1, 0.02)]
+
+
+def nw_trees():
+    """BioNJ guide trees from alignment p-distances (-a -T -i 0).  Every BioNJ run ends in the exact 4-cluster tie
+    Q(0,1) = Q(2,3) that the last bit of Eigen's vectorised column sums decides (TreeNJ.cpp:157), and for odd matrix sizes
+    the sums depend on the 16-byte alignment of each column, so these trees pin that arithmetic.  (With -m the tie is
+    decided by the last bits of the ML distances, i.e. of Eigen's EigenSolver output: not reproducible, see DESIGN.md.)"""
+    out = []
+    for (n, L, seed, sub, indel) in NW_TREE_CASES:
+        w("nwt.fa.tmp", gen.fasta(gen.gen(n, L, seed, sub=sub, indel=indel)))
+        out.append(dict(n=n, L=L, seed=seed, sub=sub, indel=indel, tree=run(["-a", "-T", "-i", "0", "nwt.fa.tmp"])))
+    os.remove("nwt.fa.tmp")
+    w("nw_trees.json", json.dumps(out, indent=0))
+
+
 def main():
     os.chdir(HERE)
+    if ONLY == "nw_trees":
+        return nw_trees()
     md5 = {}
     # c1: 8 x 120 aa (BASELINE config 1), guide tree from the reference (-T), then --fasta --tree
     w("c1.fa", gen.fasta(gen.gen(8, 120, 1)))
@@ -85,6 +111,7 @@ def main():
     w("c1.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c1.fa"]))
     w("c1.nw_p.tree", run(["-a", "-T", "-i", "0", "c1.fa"]))
     w("c2.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c2.fa"]))
+    nw_trees()
     # context-specific profiles: small synthetic library (K=50), 8x120 family
     w("K50.lib", gen.genlib(50, 7))
     w("c1.cs.out.fa", run(["--fasta", "--tree", "c1.tree", "--cs_profile", "K50.lib", "c1.fa"]))

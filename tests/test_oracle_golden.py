@@ -52,13 +52,20 @@ def test_nw_distance_pairs(oracle_build, tmp_path):
 
 
 @pytest.mark.parametrize("case,flags", [
-    # 8 taxa, ML distances: the last BioNJ join is the exact 4-taxon tie Q(0,1) == Q(2,3); which cherry wins depends on the
-    # last bit of Eigen's vectorised column sums (TreeNJ.cpp:157), i.e. on host scaffolding outside the hot path.  The
-    # alignPair counts and ML distances feeding it are pinned by test_nw_distance_pairs and the 64-taxon tree below.
-    pytest.param("c1.nw_ml.tree", ["-a", "-m"], marks=pytest.mark.xfail(reason="exact NJ tie decided by Eigen's summation order", strict=False)),
+    # 8 taxa: the last BioNJ join is the exact 4-cluster tie Q(0,1) == Q(2,3), decided by the last bit of Eigen's vectorised
+    # column sums (TreeNJ.cpp:157), which the host restates (distance.cpp eigen_column_sum)
+    ("c1.nw_ml.tree", ["-a", "-m"]),
     ("c1.nw_p.tree", ["-a"])])
 def test_nw_guide_tree_c1(oracle_build, case, flags):
     assert run_oracle(oracle_build, flags + ["-T", "-i", "0", os.path.join(GOLD, "c1.fa")]) == gold(case)
+
+
+def test_nw_guide_trees_pdist(oracle_build, tmp_path):
+    """Twelve BioNJ trees (5..30 taxa, odd and even) from alignment p-distances: identical newick, including the side of the
+    exact final tie that depends on the association and alignment of Eigen's column sums."""
+    for c in json.load(open(os.path.join(GOLD, "nw_trees.json"))):
+        (tmp_path / "t.fa").write_text(gen.fasta(gen.gen(c["n"], c["L"], c["seed"], sub=c["sub"], indel=c["indel"])))
+        assert run_oracle(oracle_build, ["-a", "-T", "-i", "0", str(tmp_path / "t.fa")]) == c["tree"], c
 
 
 def test_nw_guide_tree_c2(oracle_build):
