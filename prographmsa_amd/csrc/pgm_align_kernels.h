@@ -240,6 +240,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pgm_band_rsrc(float4 *base, ui
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+#define PGM_GLOBAL __attribute__((address_space(1)))
+typedef float pgm_v4f __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T pgm_gld(const T *p) { return *(const PGM_GLOBAL T *)(uintptr_t)p; }   // scalar global load
 template <int MODE = 0>
 __device__ __forceinline__ void pgm_store_cell(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, float Mv, float Xv, float Wv, float Yv) {
     typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
@@ -248,12 +251,31 @@ __device__ __forceinline__ void pgm_store_cell(__amdgpu_buffer_rsrc_t rsrc, uint
     if (MODE == 1) return;                                                    // timing experiments only
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane(t) * 1024u, MODE == 2 ? 0 : 16);
 }
+// Same store issued by every lane: lanes with `on == false` get an offset beyond the descriptor's num_records and the
+// buffer range check drops them.  No branch around the store, so every step issues exactly one vector memory
+// instruction, which is what lets the compiler turn the waits on the block prefetch into counted waits (vmcnt(8)).
+__device__ __forceinline__ void pgm_store_cell_masked(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, bool on, float Mv, float Xv, float Wv, float Yv) {
+    typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
+    pgm_v4u v;
+    v.x = __float_as_uint(Mv); v.y = __float_as_uint(Xv); v.z = __float_as_uint(Wv); v.w = __float_as_uint(Yv);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, on ? (uint32_t)lane * 16u : 0x80000000u, __builtin_amdgcn_readfirstlane(t) * 1024u, 16);
+}
+// Loads through global-address-space pointers (global_load, returned in issue order and counted by vmcnt) instead of
+// generic ones (flat_load, which the compiler can only wait for with vmcnt(0)).
+__device__ __forceinline__ float4 pgm_gload4(const float4 *p) {
+    const pgm_v4f v = *(const PGM_GLOBAL pgm_v4f *)(uintptr_t)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 pgm_gload_cell_wy(const float4 *p) {   // {W, Y}, device-coherent
+    const unsigned long long v = __hip_atomic_load((const PGM_GLOBAL unsigned long long *)(uintptr_t)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+}
 __device__ __forceinline__ float2 pgm_load_cell_mx(const float4 *p) {   // {M, X}
-    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load((const PGM_GLOBAL unsigned long long *)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
 }
 __device__ __forceinline__ float2 pgm_load_cell_wy(const float4 *p) {   // {W, Y}
-    const unsigned long long v = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load((const PGM_GLOBAL unsigned long long *)(uintptr_t)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
 }
 
@@ -1026,7 +1048,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     const int idx = lane + 64 * u;
                     const uint32_t col = c0 + (uint32_t)(idx / NQ);
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx < BL * NQ && col <= ncol) v = ni2q[(size_t)NQ * col + (idx % NQ)];
+                    if (idx < BL * NQ && col <= ncol) v = pgm_gload4(ni2q + (size_t)NQ * col + (idx % NQ));
                     pfq[u] = v;
                 }
             };
@@ -1045,7 +1067,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     const uint32_t st = s0 + (uint32_t)(e / HR) + (uint32_t)RC;
                     const int l = e % HR;
                     float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
-                    if (has_prev && st < tsteps) v = pgm_load_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
+                    if (has_prev && st < tsteps) v = pgm_gload_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
                     pfr[u] = v;
                 }
             };
@@ -1058,7 +1080,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
 #pragma unroll
                 for (int q = 0; q < BL / 4; ++q) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (comp && tb < nblk) v = S_band[((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q];
+                    if (comp && tb < nblk) v = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
                     pfs[q] = v;
                 }
             };
@@ -1080,11 +1102,11 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     uint32_t spins = 0;
                     const unsigned long long w0 = (trace && seen < need) ? __builtin_amdgcn_s_memrealtime() : 0ull;
                     while (seen < need) {
-                        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (seen >= need) break;
                         __builtin_amdgcn_s_sleep(4);
-                        if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             aborted = true;
                             break;
                         }
@@ -1094,7 +1116,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             };
             // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
             // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
-            auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load(&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
             auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
             // prologue: column summaries and scores of blocks 0 and 1 straight in, block 2 in flight; replay tile of
             // block 0 in, block 1 in flight
@@ -1119,21 +1141,10 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             const unsigned long long mc_start = CYCLES ? __builtin_readcyclecounter() : 0ull;
             uint32_t ticks = 0;
             for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
-                if (t0 > 0) {
-                    store_ring_block(t0 + BL);     // one block before use (helpers run ahead of this wavefront)
-                    store_s_block(t0 + BL);
-                    store_rep_block();
-                    load_ring_block(t0 + 2 * BL);
-                    load_s_block(t0 + 2 * BL);
-                    poll_collect();
-                    wait_prev(t0 + BL + BL + RC);
-                    load_rep_block(t0 + BL);
-                    poll_issue();
-                }
                 // LDS operands of a step are read one step ahead (aux2 / S of the next column are already staged; the replay
                 // tile only inside its block), so no LDS round trip sits between two steps of the chain.
                 rep_n = rep[lane & (HR - 1)];
-#pragma unroll 1
+#pragma unroll
                 for (int i = 0; i < BL; ++i) {
                     const uint32_t t = t0 + i;
                     const int xs = (int)t - lane;
@@ -1176,12 +1187,12 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                         }
                     }
                     const bool gen = active && (geny_m || genx || overflow);
-                    if (__builtin_amdgcn_ballot_w64(gen) != 0) {
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(gen) != 0, 0)) {
                         if (gen) {
-                            const uint32_t xbx = (uint32_t)J.xp2[x], xex = (uint32_t)J.xp2[x + 1];
+                            const uint32_t xbx = (uint32_t)pgm_gld(J.xp2 + x), xex = (uint32_t)pgm_gld(J.xp2 + x + 1);
                             for (uint32_t e = xby; e < xey; ++e) {
-                                const uint32_t yp = J.xc1[e];
-                                const float cy = J.xv1[e];
+                                const uint32_t yp = pgm_gld(J.xc1 + e);
+                                const float cy = pgm_gld(J.xv1 + e);
                                 const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
                                 Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
                                 if (x > 0) {
@@ -1189,15 +1200,15 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                                     Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
                                 }
                                 for (uint32_t f = xbx; f < xex; ++f) {
-                                    const uint32_t xp = J.xc2[f];
-                                    const float cx = J.xv2[f];
+                                    const uint32_t xp = pgm_gld(J.xc2 + f);
+                                    const float cx = pgm_gld(J.xv2 + f);
                                     const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
                                     Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
                                 }
                             }
                             for (uint32_t f = xbx; f < xex; ++f) {
-                                const uint32_t xp = J.xc2[f];
-                                const float cx = J.xv2[f];
+                                const uint32_t xp = pgm_gld(J.xc2 + f);
+                                const float cx = pgm_gld(J.xv2 + f);
                                 const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
                                 const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
                                 Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
@@ -1217,8 +1228,8 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                         Wv = incol ? rv.x : PGM_NEG_INF;
                         Yv = incol ? rv.y : PGM_NEG_INF;
                     }
+                    pgm_store_cell_masked(cells_rsrc, t, lane, active, Mv, Xv, Wv, Yv);
                     if (active) {
-                        pgm_store_cell(cells_rsrc, t, lane, Mv, Xv, Wv, Yv);
                         W_left = Wv;
                         X_left = Xv;
                     }
@@ -1234,7 +1245,23 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                 }
                 if (has_next) {
                     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
-                    if (lane == 0) __hip_atomic_store(&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // Stage the block after the next one.  This sits at the END of the iteration so that, on every path into
+                // it, exactly the BL cell stores of this block were issued after the prefetch loads consumed here: the
+                // compiler then waits for them with vmcnt(BL) instead of vmcnt(0), i.e. the wavefront never drains the
+                // stores it has just issued (~2 us of write-through latency per block otherwise).
+                const uint32_t t1 = t0 + BL;
+                if (t1 < tsteps) {
+                    store_ring_block(t1 + BL);     // one block before use (helpers run ahead of this wavefront)
+                    store_s_block(t1 + BL);
+                    store_rep_block();
+                    load_ring_block(t1 + 2 * BL);
+                    load_s_block(t1 + 2 * BL);
+                    poll_collect();
+                    wait_prev(t1 + BL + BL + RC);
+                    load_rep_block(t1 + BL);
+                    poll_issue();
                 }
             }
             if (CYCLES && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
