@@ -815,17 +815,18 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         }
         __syncthreads();                // "request" that ends the loaders' loop
     }
-    // reverse the two mappings in place (GraphAlign.h:520-521), all threads; thread 0's pushes are ordered by the barrier
+    // reverse the two mappings (GraphAlign.h:520-521), all threads; thread 0's pushes are ordered by the barrier.  The
+    // reversed copy goes straight to the pinned host block (posted PCIe writes, 1 KB per wavefront-iteration), so the
+    // host needs no device-to-host copy after the kernel.
     __threadfence_block();
     __syncthreads();
     const uint32_t len = T.len;
-    for (uint32_t i = (uint32_t)tid; i < len / 2; i += (uint32_t)nthreads) {
+    for (uint32_t i = (uint32_t)tid; i < len; i += (uint32_t)nthreads) {
         const uint32_t j = len - 1 - i;
-        uint32_t a = J.map1[i], b2 = J.map1[j];
-        J.map1[i] = b2; J.map1[j] = a;
-        a = J.map2[i]; b2 = J.map2[j];
-        J.map2[i] = b2; J.map2[j] = a;
+        J.hmap1[i] = J.map1[j];
+        J.hmap2[i] = J.map2[j];
     }
+    if (tid == 0) *J.hresult = *J.result;
 }
 
 #define PGM_SPIN_LIMIT (1u << 24)
@@ -1414,7 +1415,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             __syncthreads();
             if (threadIdx.x == 0) {
                 const bool ok = !aborted && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; }
+                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; *J.hresult = *J.result; }
                 tb_go = ok ? 1 : 0;
             }
             __syncthreads();

@@ -75,9 +75,9 @@ struct pgm_align_batch {
     uint8_t *d_in = nullptr;          // uploaded inputs (arena image)
     uint8_t *d_work = nullptr;        // prep outputs, brow, maps, results, scratch
     uint8_t *d_cells = nullptr;       // DP storage
-    uint8_t *d_out = nullptr;         // results + mappings (one contiguous D2H copy per fetch)
+    uint8_t *d_out = nullptr;         // device working copy of results + mappings (the walk pushes them in reverse order)
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // real sizes of the buffers taken from the context's cache
-    uint8_t *h_out = nullptr;          // pinned staging buffer of the result block (one D2H copy per fetch)
+    uint8_t *h_out = nullptr;          // pinned result block, same layout: written by the kernel itself, read by fetch
     uint8_t *h_in = nullptr;           // pinned staging buffer of the flattened inputs (one H2D copy per create)
     int *h_flag = nullptr;
     uint8_t *d_S = nullptr;           // emission scores in fill order
@@ -388,6 +388,15 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         pgm_align_batch_destroy(ctx, b);
         return fail(e == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
+    // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
+    // into it over PCIe while the kernel is still running (fetch is then a stream synchronisation, not a copy)
+    uint8_t *h_out_dev = nullptr;
+    if ((e = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST])) != hipSuccess ||
+        (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&h_out_dev, b->h_out, 0)) != hipSuccess) {
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
     for (uint32_t i = 0; i < njobs; ++i) {
         PgmJob &J = b->jobs[i];
         const Off &o = off[i];
@@ -407,6 +416,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.map1 = (uint32_t *)(ob + o.map1); J.map2 = (uint32_t *)(ob + o.map2);
         J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
         J.result = (PgmJob::Result *)(ob + o.res);
+        J.hmap1 = (uint32_t *)(h_out_dev + o.map1); J.hmap2 = (uint32_t *)(h_out_dev + o.map2);
+        J.hresult = (PgmJob::Result *)(h_out_dev + o.res);
         J.cells = (float4 *)(b->d_cells + o.cells);
         J.S = (float *)(b->d_S + s_off[i]);
         J.prog = b->d_sync + prog_off[i];
@@ -434,11 +445,13 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
         std::vector<std::vector<Item>> per_job(njobs);
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
+        auto envd = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };   // experiments only
+        const double tau_x = envd("PGM_SIM_TAU_X", 0.7), tau_c = envd("PGM_SIM_TAU_C", 0.38), eager = envd("PGM_SIM_EAGER", 0.7);
         size_t total = 0;
         double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
-            const double tau = J.has_extras ? 0.7 : 0.38;        // us per step
+            const double tau = J.has_extras ? tau_x : tau_c;     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             const uint32_t group = J.has_extras ? 1u : 4u;       // chain-only jobs: four bands per item, one per wavefront
             for (uint32_t band = 0; band < J.nb; band += group) {
@@ -479,16 +492,11 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             free_at.push(now + it.dur);
             // the longest paths of the batch are not held back: their next band gets a worker at once (it spins until the
             // predecessor is far enough, but then follows it without any queueing delay)
-            if (++next[j] < per_job[j].size()) pending.push({per_job[j][next[j]].rem > 0.7 * rmax ? now : now + it.gap, j});
+            if (++next[j] < per_job[j].size()) pending.push({per_job[j][next[j]].rem > eager * rmax ? now : now + it.gap, j});
         }
     }
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
-    if ((e = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST])) != hipSuccess ||
-        (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess) {
-        pgm_align_batch_destroy(ctx, b);
-        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
-    }
     if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 48 * items.size());
     if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
@@ -540,10 +548,11 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     if (!ctx || !b || (b->njobs && !out)) return fail(PGM_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (b->njobs == 0) { HIPCHK(hipStreamSynchronize(ctx->stream)); return PGM_OK; }
-    // results + mappings live in one contiguous device region: a single D2H copy into pinned memory (stream ordered
-    // behind the kernels), then scatter
+    // results + mappings were written into the pinned block by the kernel itself (PgmJob::hmap1/hmap2/hresult): wait for
+    // the stream, then scatter
     int rc = PGM_OK;
-    HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (getenv("PGM_FILL_DBG"))   // instrumented kernel variants leave their counters in the device block
+        HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(b->h_flag, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int aborted = *b->h_flag;

@@ -86,6 +86,10 @@ struct PgmJob {
     float *mark_score;     // [maxn]
     uint32_t *mark_prev;   // [maxn]
     struct Result { float score; uint32_t n_tr_indels; uint32_t len; int32_t status; } *result;
+    // The finished mappings (reversed into alignment order) and the result record are written straight into the batch's
+    // pinned host block by the worker that walked the traceback: no device-to-host copy after the kernel.
+    uint32_t *hmap1, *hmap2;
+    Result *hresult;
 };
 
 
