@@ -147,6 +147,11 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 // The 79 columns of T = M^T g2 the workgroup touches are staged in LDS as overlapping column PAIRS
 // {T[c][k], T[c+1][k]}: two consecutive cells of a row are then one packed multiply and one packed add per k
 // (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, the same sequential mul-then-add order as the scalar code).
+// Global-address-space accesses: pointers taken from a PgmJob in memory are generic, and generic (flat) loads / stores
+// tie vmcnt and lgkmcnt together (every LDS wait then also waits for them); these compile to global_load / global_store.
+#define PGM_GLOBAL __attribute__((address_space(1)))
+typedef float pgm_v4f __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T pgm_gld(const T *p) { return *(const PGM_GLOBAL T *)(uintptr_t)p; }   // scalar global load
 #define PGM_EM_TB 4   // step blocks per emission workgroup
 template <int DP>
 __global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
@@ -196,10 +201,12 @@ __global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__
     }
     const float ay = J.a1[yc];
     const float mi = J.sc.match_init;
+    const uint32_t nblk = J.nblk;
+    PGM_GLOBAL pgm_v4f *const Sq = (PGM_GLOBAL pgm_v4f *)(uintptr_t)J.S;
 #pragma unroll 1
     for (int w = 0; w < PGM_EM_TB; ++w) {
         const uint32_t tb = tb0 + w;
-        if (tb >= J.nblk) break;
+        if (tb >= nblk) break;
         float out[PGM_BLOCK];
 #pragma unroll
         for (int i = 0; i < PGM_BLOCK; i += 2) {
@@ -214,9 +221,9 @@ __global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__
             out[i] = pgm_emission_finish(acc.x, ay, bq[ci], mi);
             out[i + 1] = pgm_emission_finish(acc.y, ay, bq[ci + 1], mi);
         }
-        float4 *dst = (float4 *)(J.S + (((size_t)b * J.nblk + tb) * 64u + (uint32_t)l) * PGM_BLOCK);
+        PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)b * nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
 #pragma unroll
-        for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
     }
 }
 
@@ -240,9 +247,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pgm_band_rsrc(float4 *base, ui
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-#define PGM_GLOBAL __attribute__((address_space(1)))
-typedef float pgm_v4f __attribute__((ext_vector_type(4)));
-template <class T> __device__ __forceinline__ T pgm_gld(const T *p) { return *(const PGM_GLOBAL T *)(uintptr_t)p; }   // scalar global load
 template <int MODE = 0>
 __device__ __forceinline__ void pgm_store_cell(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, float Mv, float Xv, float Wv, float Yv) {
     typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
