@@ -99,7 +99,8 @@ int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 /* Staged form of the same call (what pgm_align_graphs_batch does internally):
  *   create  : flatten + upload every job's inputs to HBM, allocate the DP storage
  *   run     : launch the prep, emission and fill(+traceback) kernels on the context's stream (asynchronous)
- *   fetch   : wait, copy score / mappings back into caller memory
+ *   fetch   : wait for the stream, then copy score / mappings from the batch's pinned result block (written by the kernel
+ *             itself while it runs) into caller memory
  * bench.py times `run` with the inputs already resident. */
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                            const pgm_graph *const *g2, const pgm_model *const *model,
