@@ -2,13 +2,14 @@
 // (reference src/DistanceFactoryAlign.h:59-127 alignPair).  Exact int32 arithmetic.
 //
 // One wavefront per sequence pair, pairs pulled from a device-side work queue (atomic counter), so
-// the kernel is a persistent grid sized to the chip.  The wavefront sweeps seq2 (rows) in bands of 64
-// (lane = row) along seq1 (columns) with the same one-column-per-lane skew as the graph DP: the
+// the kernel is a persistent grid sized to the chip.  The wavefront sweeps seq2 (rows) in bands of 128
+// (two consecutive rows per lane: the lower one takes its upper neighbours from the lane's own registers, so one set
+// of DPP shifts serves two cells) along seq1 (columns) with the same one-column-per-lane skew as the graph DP: the
 // (y-1,x-1), (y-1,x) neighbours arrive by one DPP shift, (y,x-1) is the lane's own register, the symbol
 // of seq1 travels down the lanes systolically.  The reference keeps three int32 matrices (12 B/cell) for
 // its traceback; the traceback only ever asks "which of diag / X / Y equals W at this cell" (priority
 // diag > X > Y, DistanceFactoryAlign.h:100-123), so 2 direction bits per cell are stored instead,
-// 16 steps per 32-bit word, and the last row of a band is kept in a per-wave scratch row for the next band.
+// (4 bits per lane and step, 8 steps per 32-bit word), and the last row of a band is kept in a per-wave scratch row for the next band.
 #ifndef PGM_NW_KERNELS_H_
 #define PGM_NW_KERNELS_H_
 
@@ -69,18 +70,20 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
         const int8_t *s2 = A.syms + o2;
         const int L1 = __builtin_amdgcn_readfirstlane((int)(A.offs[i1 + 1] - o1));  // columns
         const int L2 = __builtin_amdgcn_readfirstlane((int)(A.offs[i2 + 1] - o2));  // rows
-        const int nb = (L2 + 63) / 64;
+        const int nb = (L2 + 127) / 128;
         const int tsteps = L1 + 63;
-        const int twords = (tsteps + 15) / 16;
+        const int twords = (tsteps + 7) / 8;
 
         for (int b = 0; b < nb; ++b) {
-            const int y = 64 * b + lane + 1;  // 1..L2
-            const bool rowvalid = y <= L2;
-            const int sy = rowvalid ? (int)s2[y - 1] : 0;
-            int W_left = go + (y - 1) * ge;           // W(y,0) = Y(y,0)
-            int X_left = MINF;                        // X(y,0)
-            int W_diag = (y == 1) ? 0 : go + (y - 2) * ge;  // W(y-1,0)
-            int W_o = MINF, Y_o = MINF, sx_o = 0;
+            // lane l owns the two rows yA = 128 b + 2 l + 1 and yB = yA + 1: row B takes its upper neighbours from the lane's
+            // own registers, so one set of DPP shifts serves two cells
+            const int yA = 128 * b + 2 * lane + 1, yB = yA + 1;  // 1..L2
+            const bool validA = yA <= L2, validB = yB <= L2;
+            const int syA = validA ? (int)s2[yA - 1] : 0, syB = validB ? (int)s2[yB - 1] : 0;
+            int WA_left = go + (yA - 1) * ge, WB_left = go + (yB - 1) * ge;   // W(y,0) = Y(y,0)
+            int XA_left = MINF, XB_left = MINF;                               // X(y,0)
+            int WA_diag = (yA == 1) ? 0 : go + (yA - 2) * ge;                 // W(yA-1,0)
+            int W_o = MINF, Y_o = MINF, sx_o = 0;                             // row B's outputs, consumed by the lane below
             uint32_t word = 0;
             for (int t0 = 0; t0 < tsteps; t0 += 64) {
                 // block prefetch for lane 0: seq1 symbols and the row above (columns t0+1 .. t0+64)
@@ -95,32 +98,41 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                 for (int i = 0; i < tend; ++i) {
                     const int t = t0 + i;
                     const int x = t - lane + 1;  // 1..L1
-                    const bool active = rowvalid && x >= 1 && x <= L1;
+                    const bool incol = x >= 1 && x <= L1;
                     const int sx = pgm_dpp_shr1_i(sx_o, __builtin_amdgcn_readlane(pf_s, i));
                     const int W_up = pgm_dpp_shr1_i(W_o, __builtin_amdgcn_readlane(pf_w, i));
                     const int Y_up = pgm_dpp_shr1_i(Y_o, __builtin_amdgcn_readlane(pf_y, i));
-                    const int sidx = sy + sd * sx;  // scoring_matrix(s2(y), s1(x))
-                    const int dc = W_diag + nw_score[sidx];   // (sx, sy are valid symbols in every lane, also the idle ones)
-                    const int Xv = max(X_left + ge, W_left + go);
-                    const int Yv = max(Y_up + ge, W_up + go);
-                    const int xy = max(Xv, Yv);
-                    const int Wv = max(xy, dc);
-                    const uint32_t dir = (dc >= xy) ? 0u : (Xv >= Yv ? 1u : 2u);
-                    word |= dir << ((t & 15) * 2);
-                    if ((t & 15) == 15 || t == tsteps - 1) {
-                        dirs[((size_t)b * twords + (t >> 4)) * 64 + lane] = word;
+                    const int so = sd * sx;   // (sx, sy are valid symbols in every lane, also the idle ones)
+                    // row A
+                    const int dcA = WA_diag + nw_score[syA + so];   // scoring_matrix(s2(y), s1(x))
+                    const int XvA = max(XA_left + ge, WA_left + go);
+                    const int YvA = max(Y_up + ge, W_up + go);
+                    const int xyA = max(XvA, YvA);
+                    const int WvA = max(xyA, dcA);
+                    const uint32_t dirA = (dcA >= xyA) ? 0u : (XvA >= YvA ? 1u : 2u);
+                    // row B: the row above is row A of this lane (same column: just computed; previous column: WA_left)
+                    const int dcB = WA_left + nw_score[syB + so];
+                    const int XvB = max(XB_left + ge, WB_left + go);
+                    const int YvB = max(YvA + ge, WvA + go);
+                    const int xyB = max(XvB, YvB);
+                    const int WvB = max(xyB, dcB);
+                    const uint32_t dirB = (dcB >= xyB) ? 0u : (XvB >= YvB ? 1u : 2u);
+                    word |= (dirA | (dirB << 2)) << ((t & 7) * 4);
+                    if ((t & 7) == 7 || t == tsteps - 1) {
+                        dirs[((size_t)b * twords + (t >> 3)) * 64 + lane] = word;
                         word = 0;
                     }
-                    if (active) {
-                        W_left = Wv;
-                        X_left = Xv;
-                        if (lane == 63 && b + 1 < nb) brow[x] = make_int2(Wv, Yv);
+                    if (incol) {
+                        // rows beyond L2 compute on, nobody reads them (row B invalid implies every lane below is invalid)
+                        WA_left = WvA; XA_left = XvA;
+                        WB_left = WvB; XB_left = XvB;
+                        if (lane == 63 && b + 1 < nb) brow[x] = make_int2(WvB, YvB);
                     }
-                    if (x >= 1) W_diag = W_up;  // keep W(y-1,0) until the lane reaches column 1
-                    // a lane's outputs are only consumed by the lane below one step later, which is active only if this one
-                    // was: idle lanes may pass on whatever they computed
-                    W_o = Wv;
-                    Y_o = Yv;
+                    if (x >= 1) WA_diag = W_up;  // keep W(yA-1,0) until the lane reaches column 1
+                    // a lane's outputs are only consumed by the lane below one step later, which is in a column only if this
+                    // one was: idle lanes may pass on whatever they computed
+                    W_o = WvB;
+                    Y_o = YvB;
                     sx_o = sx;
                 }
             }
@@ -134,10 +146,10 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
             int32_t *cnt = A.counts + (size_t)p * A.dim * A.dim;
             int y = L2, x = L1;
             while (y != 0 && x != 0) {
-                const int bb = (y - 1) >> 6, l = (y - 1) & 63;
+                const int bb = (y - 1) >> 7, r = (y - 1) & 127, l = r >> 1;
                 const int t = (x - 1) + l;
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)dirs[((size_t)bb * twords + (t >> 4)) * 64 + l]);
-                const uint32_t dir = (w >> ((t & 15) * 2)) & 3u;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)dirs[((size_t)bb * twords + (t >> 3)) * 64 + l]);
+                const uint32_t dir = (w >> ((t & 7) * 4 + (r & 1) * 2)) & 3u;
                 if (dir == 0) {
                     const int a = __builtin_amdgcn_readfirstlane((int)s1[x - 1]);
                     const int c = __builtin_amdgcn_readfirstlane((int)s2[y - 1]);
