@@ -35,8 +35,11 @@ struct PgmNwArgs {
     int32_t *status;         // set to PGM_ERR_BACKTRACK if a traceback finds no matching source
 };
 
-__device__ __forceinline__ int pgm_dpp_shr1_i(int src, int lane0_value) {
+__device__ __forceinline__ int pgm_dpp_shr1_i(int src, int lane0_value) {   // lane l <- src of lane l-1; lane 0 keeps lane0_value
     return __builtin_amdgcn_update_dpp(lane0_value, src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int pgm_dpp_rol1_i(int src) {                    // lane l <- src of lane l+1 (wave_rol:1)
+    return __builtin_amdgcn_update_dpp(src, src, 0x134, 0xf, 0xf, false);
 }
 
 template <int WAVES>
@@ -99,9 +102,12 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                     const int t = t0 + i;
                     const int x = t - lane + 1;  // 1..L1
                     const bool incol = x >= 1 && x <= L1;
-                    const int sx = pgm_dpp_shr1_i(sx_o, __builtin_amdgcn_readlane(pf_s, i));
-                    const int W_up = pgm_dpp_shr1_i(W_o, __builtin_amdgcn_readlane(pf_w, i));
-                    const int Y_up = pgm_dpp_shr1_i(Y_o, __builtin_amdgcn_readlane(pf_y, i));
+                    // lane 0's inputs of step i were prefetched by lane i: the prefetch registers rotate one lane down per
+                    // step, so lane 0 always holds the current ones (one DPP instead of readlane + move)
+                    const int sx = pgm_dpp_shr1_i(sx_o, pf_s);
+                    const int W_up = pgm_dpp_shr1_i(W_o, pf_w);
+                    const int Y_up = pgm_dpp_shr1_i(Y_o, pf_y);
+                    pf_s = pgm_dpp_rol1_i(pf_s); pf_w = pgm_dpp_rol1_i(pf_w); pf_y = pgm_dpp_rol1_i(pf_y);
                     const int so = sd * sx;   // (sx, sy are valid symbols in every lane, also the idle ones)
                     // row A
                     const int dcA = WA_diag + nw_score[syA + so];   // scoring_matrix(s2(y), s1(x))
