@@ -1369,6 +1369,10 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                         }
                     }
                 };
+                // a band without row extras (most bands of a light merged graph): nothing to evaluate, only keep the ticks
+                if (nent == 0) {
+                    for (uint32_t t = 0; t < tend; ++t) tick();
+                } else {
                 fetch_cols(0);
                 for (uint32_t t = 0; t < tend; ++t) {
                     const uint32_t t8 = t << 8;
@@ -1403,6 +1407,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     const unsigned long long hcb = CYCLES ? __builtin_readcyclecounter() : 0ull;
                     tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
                     if (CYCLES) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
+                }
                 }
             }
             if (CYCLES && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
