@@ -964,6 +964,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         const uint32_t dymax = (fy >> 8) & 255u;
         const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
         bool geny_m = geny;   // main wavefront: plus the rows whose entries overflowed the list
+        bool no_ent = true;   // main wavefront: the band has no row-extra entries (helpers 2 and 3 contribute nothing)
         const bool ykill = (fy & 16u) != 0;
         uint32_t rk8[PGM_KX], lk4[PGM_KX];
         float cyv[PGM_KX];
@@ -1138,6 +1139,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             if (need_help) {
                 __syncthreads();   // history / counters initialised, first two blocks staged, entry list built
                 geny_m = geny || ovf[lane] != 0;
+                no_ent = __builtin_amdgcn_readfirstlane(el_cnt) == 0;   // helpers 2/3 idle: their result slots stay -inf
             }
 
             unsigned long long mcyc_wait = 0;
@@ -1183,8 +1185,12 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                         if (CYCLES) mcyc_wait += __builtin_readcyclecounter() - mc0;
                         const float *r1 = res1 + (t & 1u) * (2 * 64) + lane;
                         float *ra = resA + (t & 1u) * (2 * 64) + lane;
-                        const float m1 = r1[0], x1 = r1[64], m2 = ra[0], y2 = ra[64];
-                        ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 2
+                        const float m1 = r1[0], x1 = r1[64];
+                        float m2 = PGM_NEG_INF, y2 = PGM_NEG_INF;
+                        if (!no_ent) {
+                            m2 = ra[0]; y2 = ra[64];
+                            ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 2
+                        }
                         if (!overflow) {
                             Mv = fmaxf(Mv, fmaxf(m1, m2));
                             Xv = fmaxf(Xv, x1);
@@ -1370,7 +1376,8 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
                     }
                 };
                 // a band without row extras (most bands of a light merged graph): nothing to evaluate, only keep the ticks
-                if (nent == 0) {
+                // (helper 3 evaluates the pairs with column extras 3..6: idle too if no column of the job has more than three)
+                if (nent == 0 || (h == 2 && J.max_cx <= 3u)) {
                     for (uint32_t t = 0; t < tend; ++t) tick();
                 } else {
                 fetch_cols(0);

@@ -145,6 +145,7 @@ namespace {
 struct SideOff {
     size_t sites, ni, xp, xc, xv, pp, pc, pv, pu;
     uint32_t nodes_with_extras;
+    uint32_t max_on_chip;   // largest number of extras of one node that are served from the on-chip history (0..7)
 };
 
 static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
@@ -202,7 +203,8 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
         if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 16u;  // interior node without predecessors
     }
     o.nodes_with_extras = 0;
-    for (uint32_t v = 0; v < n; ++v) o.nodes_with_extras += (xp[v + 1] > xp[v]);
+    o.max_on_chip = 0;
+    for (uint32_t v = 0; v < n; ++v) { o.nodes_with_extras += (xp[v + 1] > xp[v]); o.max_on_chip = std::max(o.max_on_chip, ni[v].flags & 7u); }
     // at least one element each so that pointers are valid
     if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
     if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
@@ -357,6 +359,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 Off &o = off[i];
                 if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); continue; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
+                J.max_cx = o.s2.max_on_chip;
                 o.M = A.put(model[i]->M, sizeof(double) * J.dim * J.dim);
                 o.pi = A.put(model[i]->pi, sizeof(double) * J.dim);
                 if (A.overflow) bad.store((int)i);

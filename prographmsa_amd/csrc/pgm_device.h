@@ -50,6 +50,7 @@ struct PgmJob {
     uint32_t tsteps;       // steps per band = ncol + 63
     uint32_t maxn;         // max(n1,n2)
     uint32_t has_extras;   // some node of either graph has a predecessor other than its chain neighbour
+    uint32_t max_cx;       // largest number of on-chip extras of a column (node of graph 2): helper 3 only has work if > 3
     pgm_scores sc;
 
     // inputs as uploaded
