@@ -64,6 +64,20 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
     float *pif = prep_lds + D * D;
     float *nl = pif + D;
     const uint32_t nn = min((uint32_t)NODES, n - v0);
+    {   // predecessor records of this slice's nodes for the traceback (PgmTbNode)
+        const int32_t *pp = first ? J.pp1 : J.pp2;
+        const uint32_t *pc = first ? J.pc1 : J.pc2, *pu = first ? J.pu1 : J.pu2;
+        const float *pv = first ? J.pv1 : J.pv2;
+        PgmTbNode *rec = (first ? J.tb1 : J.tb2) + v0;
+        for (uint32_t i = threadIdx.x; i < nn * PGM_TB_PK; i += NODES) {
+            const uint32_t node = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const int32_t eb = pp[v0 + node];
+            const uint32_t cnt = (uint32_t)(pp[v0 + node + 1] - eb);
+            const int32_t e = cnt == 0u ? 0 : eb + (int32_t)min(k, cnt - 1u);
+            if (k == 0) rec[node].cnt = cnt;
+            rec[node].c[k] = pc[e]; rec[node].v[k] = pv[e]; rec[node].u[k] = pu[e];
+        }
+    }
     if (!first) for (uint32_t i = threadIdx.x; i < D * D; i += NODES) Mf[i] = (float)J.M[i];
     for (uint32_t i = threadIdx.x; i < D; i += NODES) pif[i] = (float)J.pi[i];
     const double *src = (first ? J.sites1 : J.sites2) + (size_t)D * v0;
@@ -348,7 +362,6 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
 #define PGM_TB_T 32        // tile edge (rows and columns)
 #define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's (half of it for chain-only jobs)
 #define PGM_TB_LK 4        // an M-state link is precomputed for cells whose two nodes have at most this many predecessors each
-#define PGM_TB_PK 8        // predecessor entries per node kept in the tile (nodes with more are read from memory)
 struct PgmTbLds {
     float4 cell[PGM_TB_T * PGM_TB_T];          // {M, X, W, Y} of rows ty0.., columns tx0..
     float S[PGM_TB_T * PGM_TB_T];
@@ -392,25 +405,17 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             cv[u] = J.cells[pgm_cell_index(J, yy, xx)];
             sv[u] = pgm_emission_at(J, yy, xx);
         }
-        int32_t eb[NP];
-        uint32_t cnt[NP];
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK;
-            const bool row = slot < TT;
-            const uint32_t v = min(row ? ty0 + slot : tx0 + (slot - TT), (row ? n1 : n2) - 1);
-            const PgmPred &P = row ? P1 : P2;
-            eb[u] = P.pp[v];
-            cnt[u] = (uint32_t)(P.pp[v + 1] - eb[u]);
-        }
-        uint32_t ec[NP], eu[NP];
+        // predecessor entries: slot = row (0..TT-1) or column (TT..2TT-1) of the tile, k = entry; straight from the
+        // per-node records (same round trip as the cells)
+        uint32_t cnt[NP], ec[NP], eu[NP];
         float ev[NP];
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
-            const PgmPred &P = slot < TT ? P1 : P2;
-            const int32_t e = cnt[u] == 0u ? 0 : eb[u] + (int32_t)min(k, cnt[u] - 1u);
-            ec[u] = P.pc[e]; ev[u] = P.pv[e]; eu[u] = P.pu[e];
+            const bool row = slot < TT;
+            const uint32_t v = min(row ? ty0 + slot : tx0 + (slot - TT), (row ? n1 : n2) - 1);
+            const PgmTbNode *r = (row ? J.tb1 : J.tb2) + v;
+            cnt[u] = r->cnt; ec[u] = r->c[k]; ev[u] = r->v[k]; eu[u] = r->u[k];
         }
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
@@ -667,7 +672,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         // graphs are 1 node back; in merged graphs most skip edges span a few nodes (farther ones are read from memory)
         const uint32_t margin = J.has_extras ? 4u : 1u;
         uint32_t guard = 0;
-        unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0;
+        unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0, st_stage = 0;
         bool score_stale = false;
         while ((x != 0 || y != 0) && status == PGM_OK) {
             if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
@@ -686,6 +691,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 __syncthreads();        // request posted
                 stage();
                 __syncthreads();        // cells, scores, predecessor lists staged
+                if (stat) st_stage += __builtin_amdgcn_s_memrealtime() - r0;
                 links();
                 __syncthreads();        // successor table complete
                 if (stat) { st_reload += __builtin_amdgcn_s_memrealtime() - r0; ++st_nreload; }
@@ -815,7 +821,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             J.result->status = status;
             T.len = mo.len;
             T.req = 2;
-            if (stat) { stat[0] = st_reload; stat[1] = (st_nreload << 32) | st_slow; }
+            if (stat) { stat[0] = (st_stage << 32) | st_reload; stat[1] = (st_nreload << 32) | st_slow; }
         }
         __syncthreads();                // "request" that ends the loaders' loop
     }

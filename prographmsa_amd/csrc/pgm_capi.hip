@@ -288,7 +288,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     DevLayout W, C, O, SL;
     size_t sync_ints = 4;   // [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
     std::vector<size_t> prog_off(njobs), s_off(njobs);
-    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells; };
+    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2; };
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
     // pass 1 (serial, O(jobs)): sizes, device layouts, and an upper bound of each job's flattened input
@@ -330,6 +330,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         o.aux2 = W.take(sizeof(float) * (size_t)J.n2);
         o.map1 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
         o.map2 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
+        o.tb1 = W.take(sizeof(PgmTbNode) * (size_t)J.n1);
+        o.tb2 = W.take(sizeof(PgmTbNode) * (size_t)J.n2);
         o.ms = W.take(4 * (size_t)J.maxn);
         o.mp = W.take(4 * (size_t)J.maxn);
         o.res = O.take(sizeof(PgmJob::Result), 16);
@@ -418,6 +420,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.t2 = (float *)(w + o.t2); J.b2 = (float *)(w + o.aux2);
         J.map1 = (uint32_t *)(ob + o.map1); J.map2 = (uint32_t *)(ob + o.map2);
         J.mark_score = (float *)(w + o.ms); J.mark_prev = (uint32_t *)(w + o.mp);
+        J.tb1 = (PgmTbNode *)(w + o.tb1); J.tb2 = (PgmTbNode *)(w + o.tb2);
         J.result = (PgmJob::Result *)(ob + o.res);
         J.hmap1 = (uint32_t *)(h_out_dev + o.map1); J.hmap2 = (uint32_t *)(h_out_dev + o.map2);
         J.hresult = (PgmJob::Result *)(h_out_dev + o.res);

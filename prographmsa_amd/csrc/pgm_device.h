@@ -42,6 +42,18 @@ struct PgmNodeInfo {
 // cells[((b * tsteps) + t) * 64 + l]  — every wave-level store is one contiguous 768 B run.
 // Rows 0..n1-2 and columns 0..n2-2 are stored (the END row/column are never written by the reference
 // either); row 0 / column 0 are the border initialisation of GraphAlign.h:212-234.
+// Predecessor record of one node for the traceback's tile staging: the first PGM_TB_PK entries of the node's list in
+// PredIterator order at a fixed address (no row-pointer indirection, i.e. one memory round trip less per tile).  Built
+// by the prep kernel from the CSR.  Slots beyond the count repeat the last entry (every slot is a valid candidate read).
+#define PGM_TB_PK 8
+struct PgmTbNode {
+    uint32_t cnt;                 // full predecessor count (may exceed PGM_TB_PK: the walker then uses the CSR lists)
+    uint32_t c[PGM_TB_PK];        // predecessor node
+    float v[PGM_TB_PK];           // edge cost
+    uint32_t u[PGM_TB_PK];        // 0 for a regular edge, else 0x80000000 | repeat units
+    uint32_t pad[7];              // 128 bytes
+};
+
 struct PgmJob {
     uint32_t n1, n2;       // node counts incl. START/END
     uint32_t dim, dp;      // alphabet size and padded size (multiple of 4)
@@ -68,6 +80,7 @@ struct PgmJob {
     const uint32_t *pu1, *pu2;       // 0 for a regular edge, else 0x80000000 | repeat units
 
     // produced by the prep kernel
+    PgmTbNode *tb1, *tb2;  // [n1], [n2] predecessor records for the traceback
     float *g1f;            // [n1][dp]  float(sites1), node-major, zero padded
     float *a1;             // [n1]      g1^T pi
     float *t2;             // [n2][dp]  T = M^T g2

@@ -40,7 +40,8 @@ for i in late:
     j, bd = items[i]
     print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 47) // 48, start[i], bend[i], tend[i]))
 tbi = np.where(tend > 0)[0]
-rel = raw[tbi, 4].astype(np.float64) / 100.0
+rel = (raw[tbi, 4] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
+stg = (raw[tbi, 4] >> np.uint64(32)).astype(np.float64) / 100.0   # of which: loads -> LDS (the rest is the link pass)
 nrel = (raw[tbi, 5] >> np.uint64(32)).astype(np.float64)
 slow = (raw[tbi, 5] & np.uint64(0xffffffff)).astype(np.float64)
 plen = np.array([sizes[items[i, 0]].sum() for i in tbi], dtype=np.float64)
@@ -50,7 +51,8 @@ for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs
             print("traceback %-10s: %3d jobs, mean %.0f us, of which tile staging %.0f us in %.0f tiles (%.1f us/tile); slow steps %.0f of ~%.0f nodes; walking %.3f us/node" % (
                 nm, mm.sum(), tb[tbi][mm].mean(), rel[mm].mean(), nrel[mm].mean(), (rel[mm] / nrel[mm]).mean(), slow[mm].mean(), plen[mm].mean(), ((tb[tbi][mm] - rel[mm]) / plen[mm]).mean()))
 ri = [k for k, i in enumerate(tbi) if items[i, 0] == np.argmax(sizes[:, 0] * sizes[:, 1])][0]
-print("root traceback: %.0f us, tile staging %.0f us in %.0f tiles (%.1f us/tile), slow steps %.0f" % (tb[tbi][ri], rel[ri], nrel[ri], rel[ri] / nrel[ri], slow[ri]))
+print("root traceback: %.0f us, tile staging %.0f us (loads -> LDS %.0f us, links %.0f us) in %.0f tiles (%.1f us/tile), slow steps %.0f" % (tb[tbi][ri], rel[ri], stg[ri], rel[ri] - stg[ri], nrel[ri], rel[ri] / nrel[ri], slow[ri]))
+print("all merged: loads -> LDS %.1f us/tile, links %.1f us/tile; chain-only: %.1f / %.1f" % ((stg[~m] / nrel[~m]).mean(), ((rel[~m] - stg[~m]) / nrel[~m]).mean(), (stg[m] / nrel[m]).mean(), ((rel[m] - stg[m]) / nrel[m]).mean()))
 # per-job: first start, last end
 for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
