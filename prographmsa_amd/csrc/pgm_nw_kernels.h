@@ -2,19 +2,21 @@
 // (reference src/DistanceFactoryAlign.h:59-127 alignPair).  Exact int32 arithmetic.
 //
 // One wavefront per sequence pair, pairs pulled from a device-side work queue (atomic counter), so
-// the kernel is a persistent grid sized to the chip.  The wavefront sweeps seq2 (rows) in bands of 128
-// (two consecutive rows per lane: the lower one takes its upper neighbours from the lane's own registers, so one set
-// of DPP shifts serves two cells) along seq1 (columns) with the same one-column-per-lane skew as the graph DP: the
+// the kernel is a persistent grid sized to the chip.  The wavefront sweeps seq2 (rows) in bands of 64 R
+// (R = PGM_NW_RPL consecutive rows per lane: only the first takes its upper neighbours from the lane above, the others
+// from the lane's own registers, so one set of DPP shifts serves R cells) along seq1 (columns) with the same one-column-per-lane skew as the graph DP: the
 // (y-1,x-1), (y-1,x) neighbours arrive by one DPP shift, (y,x-1) is the lane's own register, the symbol
 // of seq1 travels down the lanes systolically.  The reference keeps three int32 matrices (12 B/cell) for
 // its traceback; the traceback only ever asks "which of diag / X / Y equals W at this cell" (priority
 // diag > X > Y, DistanceFactoryAlign.h:100-123), so 2 direction bits per cell are stored instead,
-// (4 bits per lane and step, 8 steps per 32-bit word), and the last row of a band is kept in a per-wave scratch row for the next band.
+// (2 R bits per lane and step, 16 / R steps per 32-bit word), and the last row of a band is kept in a per-wave scratch row for the next band.
 #ifndef PGM_NW_KERNELS_H_
 #define PGM_NW_KERNELS_H_
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#define PGM_NW_RPL 8   // rows of seq2 per lane (1, 2, 4 or 8: 2 R direction bits per lane and step)
 
 struct PgmNwArgs {
     uint32_t dim;            // alphabet size D; scoring matrix is (D+1)^2 column-major
@@ -73,20 +75,25 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
         const int8_t *s2 = A.syms + o2;
         const int L1 = __builtin_amdgcn_readfirstlane((int)(A.offs[i1 + 1] - o1));  // columns
         const int L2 = __builtin_amdgcn_readfirstlane((int)(A.offs[i2 + 1] - o2));  // rows
-        const int nb = (L2 + 127) / 128;
+        constexpr int R = PGM_NW_RPL, BR = 64 * R;   // rows per lane, rows per band
+        constexpr int SPW = 16 / R;                  // steps per 32-bit direction word (2 bits per cell)
+        const int nb = (L2 + BR - 1) / BR;
         const int tsteps = L1 + 63;
-        const int twords = (tsteps + 7) / 8;
+        const int twords = (tsteps + SPW - 1) / SPW;
 
         for (int b = 0; b < nb; ++b) {
-            // lane l owns the two rows yA = 128 b + 2 l + 1 and yB = yA + 1: row B takes its upper neighbours from the lane's
-            // own registers, so one set of DPP shifts serves two cells
-            const int yA = 128 * b + 2 * lane + 1, yB = yA + 1;  // 1..L2
-            const bool validA = yA <= L2, validB = yB <= L2;
-            const int syA = validA ? (int)s2[yA - 1] : 0, syB = validB ? (int)s2[yB - 1] : 0;
-            int WA_left = go + (yA - 1) * ge, WB_left = go + (yB - 1) * ge;   // W(y,0) = Y(y,0)
-            int XA_left = MINF, XB_left = MINF;                               // X(y,0)
-            int WA_diag = (yA == 1) ? 0 : go + (yA - 2) * ge;                 // W(yA-1,0)
-            int W_o = MINF, Y_o = MINF, sx_o = 0;                             // row B's outputs, consumed by the lane below
+            // lane l owns the R consecutive rows y0 + r, y0 = BR b + R l + 1: only row 0 takes its upper neighbours from
+            // the lane above (DPP), the others from the lane's own registers, so one set of shifts serves R cells
+            const int y0 = BR * b + R * lane + 1;  // 1..L2
+            int sy[R], W_left[R], X_left[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                sy[r] = (y0 + r <= L2) ? (int)s2[y0 + r - 1] : 0;
+                W_left[r] = go + (y0 + r - 1) * ge;   // W(y,0) = Y(y,0)
+                X_left[r] = MINF;                     // X(y,0)
+            }
+            int W_diag0 = (y0 == 1) ? 0 : go + (y0 - 2) * ge;   // W(y0-1,0)
+            int W_o = MINF, Y_o = MINF, sx_o = 0;               // the last row's outputs, consumed by the lane below
             uint32_t word = 0;
             for (int t0 = 0; t0 < tsteps; t0 += 64) {
                 // block prefetch for lane 0: seq1 symbols and the row above (columns t0+1 .. t0+64)
@@ -105,40 +112,42 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                     // lane 0's inputs of step i were prefetched by lane i: the prefetch registers rotate one lane down per
                     // step, so lane 0 always holds the current ones (one DPP instead of readlane + move)
                     const int sx = pgm_dpp_shr1_i(sx_o, pf_s);
-                    const int W_up = pgm_dpp_shr1_i(W_o, pf_w);
-                    const int Y_up = pgm_dpp_shr1_i(Y_o, pf_y);
+                    const int W_up0 = pgm_dpp_shr1_i(W_o, pf_w);
+                    const int Y_up0 = pgm_dpp_shr1_i(Y_o, pf_y);
                     pf_s = pgm_dpp_rol1_i(pf_s); pf_w = pgm_dpp_rol1_i(pf_w); pf_y = pgm_dpp_rol1_i(pf_y);
                     const int so = sd * sx;   // (sx, sy are valid symbols in every lane, also the idle ones)
-                    // row A
-                    const int dcA = WA_diag + nw_score[syA + so];   // scoring_matrix(s2(y), s1(x))
-                    const int XvA = max(XA_left + ge, WA_left + go);
-                    const int YvA = max(Y_up + ge, W_up + go);
-                    const int xyA = max(XvA, YvA);
-                    const int WvA = max(xyA, dcA);
-                    const uint32_t dirA = (dcA >= xyA) ? 0u : (XvA >= YvA ? 1u : 2u);
-                    // row B: the row above is row A of this lane (same column: just computed; previous column: WA_left)
-                    const int dcB = WA_left + nw_score[syB + so];
-                    const int XvB = max(XB_left + ge, WB_left + go);
-                    const int YvB = max(YvA + ge, WvA + go);
-                    const int xyB = max(XvB, YvB);
-                    const int WvB = max(xyB, dcB);
-                    const uint32_t dirB = (dcB >= xyB) ? 0u : (XvB >= YvB ? 1u : 2u);
-                    word |= (dirA | (dirB << 2)) << ((t & 7) * 4);
-                    if ((t & 7) == 7 || t == tsteps - 1) {
-                        dirs[((size_t)b * twords + (t >> 3)) * 64 + lane] = word;
+                    int W_up = W_up0, Y_up = Y_up0, W_dg = W_diag0;
+                    uint32_t dbits = 0;
+                    int Wn[R], Xn[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int dc = W_dg + nw_score[sy[r] + so];   // scoring_matrix(s2(y), s1(x))
+                        const int Xv = max(X_left[r] + ge, W_left[r] + go);
+                        const int Yv = max(Y_up + ge, W_up + go);
+                        const int xy = max(Xv, Yv);
+                        const int Wv = max(xy, dc);
+                        dbits |= ((dc >= xy) ? 0u : (Xv >= Yv ? 1u : 2u)) << (2 * r);
+                        // the next row of this lane: the row above it is this one (same column: just computed; previous
+                        // column: W_left before the update)
+                        W_dg = W_left[r]; W_up = Wv; Y_up = Yv;
+                        Wn[r] = Wv; Xn[r] = Xv;
+                    }
+                    word |= dbits << ((t % SPW) * 2 * R);
+                    if ((t % SPW) == SPW - 1 || t == tsteps - 1) {
+                        dirs[((size_t)b * twords + (t / SPW)) * 64 + lane] = word;
                         word = 0;
                     }
                     if (incol) {
-                        // rows beyond L2 compute on, nobody reads them (row B invalid implies every lane below is invalid)
-                        WA_left = WvA; XA_left = XvA;
-                        WB_left = WvB; XB_left = XvB;
-                        if (lane == 63 && b + 1 < nb) brow[x] = make_int2(WvB, YvB);
+                        // rows beyond L2 compute on, nobody reads them (an invalid row implies everything below it is invalid)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { W_left[r] = Wn[r]; X_left[r] = Xn[r]; }
+                        if (lane == 63 && b + 1 < nb) brow[x] = make_int2(W_up, Y_up);
                     }
-                    if (x >= 1) WA_diag = W_up;  // keep W(yA-1,0) until the lane reaches column 1
+                    if (x >= 1) W_diag0 = W_up0;  // keep W(y0-1,0) until the lane reaches column 1
                     // a lane's outputs are only consumed by the lane below one step later, which is in a column only if this
                     // one was: idle lanes may pass on whatever they computed
-                    W_o = WvB;
-                    Y_o = YvB;
+                    W_o = W_up;
+                    Y_o = Y_up;
                     sx_o = sx;
                 }
             }
@@ -152,10 +161,10 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
             int32_t *cnt = A.counts + (size_t)p * A.dim * A.dim;
             int y = L2, x = L1;
             while (y != 0 && x != 0) {
-                const int bb = (y - 1) >> 7, r = (y - 1) & 127, l = r >> 1;
+                const int bb = (y - 1) / BR, rr = (y - 1) % BR, l = rr / R;
                 const int t = (x - 1) + l;
-                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)dirs[((size_t)bb * twords + (t >> 3)) * 64 + l]);
-                const uint32_t dir = (w >> ((t & 7) * 4 + (r & 1) * 2)) & 3u;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)dirs[((size_t)bb * twords + (t / SPW)) * 64 + l]);
+                const uint32_t dir = (w >> ((t % SPW) * 2 * R + (rr % R) * 2)) & 3u;
                 if (dir == 0) {
                     const int a = __builtin_amdgcn_readfirstlane((int)s1[x - 1]);
                     const int c = __builtin_amdgcn_readfirstlane((int)s2[y - 1]);
