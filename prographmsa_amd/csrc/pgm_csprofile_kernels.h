@@ -14,9 +14,7 @@
 
 struct PgmCsArgs {
     uint32_t K, ncols, nseq;
-    const double *lprofiles;  // [K][ncols][21]
-    const double *centre;     // [K][20]
-    const double *priors;     // [K]
+    const double *lprofiles;  // [K] records of (ncols + 1) * 22 doubles: ncols x 22 window entries, 20 centre values, prior, pad
     const int8_t *syms;       // 0..19, 20 = invalid
     const uint32_t *offs;     // nseq+1
     const uint32_t *pos_seq;  // sequence index of every residue (flattened over all sequences)
@@ -28,15 +26,17 @@ struct PgmCsArgs {
     uint32_t total;           // total residues
 };
 
-// The library (K x ncols x 21 doubles, 8.7 MB for K = 4000) is streamed through LDS in chunks of PGM_CS_KC profiles: every
-// thread of the workgroup needs every profile, and its 13 window look-ups per profile are gathers (one of 21 entries per
-// column) that LDS serves at a fraction of the L2 cost.  In LDS every column has a 22nd entry holding 0.0 for positions
-// outside the sequence (which the reference skips): pk + 0.0 == pk, so the sum is the reference's without a branch per column.
+// The library (8.7 MB for K = 4000) is streamed through LDS in chunks of PGM_CS_KC profiles: every thread of the
+// workgroup needs every profile, and its 13 window look-ups per profile are gathers (one of 21 entries per column) that
+// LDS serves at a fraction of the L2 cost.  pgm_csprofile_load stores it as one record of (ncols + 1) * 22 doubles per
+// profile — ncols window columns of 22 entries (the 22nd holds 0.0 for positions outside the sequence, which the
+// reference skips: pk + 0.0 == pk, so the sum is the reference's without a branch per column), then the 20 centre
+// values, the prior and a pad — so that staging a chunk is a straight 16-byte copy.
 #define PGM_CS_KC 8
+#define PGM_CS_U 2    // profiles evaluated together (independent chains); divides PGM_CS_KC
 __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
-    extern __shared__ double cs_lds[];   // [KC][ncols*22] window tables, [KC][20] centre columns, [KC] priors
-    const uint32_t tab = A.ncols * 22u, gtab = A.ncols * 21u;
-    double *s_lp = cs_lds, *s_ce = cs_lds + PGM_CS_KC * tab, *s_pr = s_ce + PGM_CS_KC * 20;
+    extern __shared__ double cs_lds[];   // [KC] records
+    const uint32_t tab = A.ncols * 22u, rec = tab + 22u;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = gid < A.total;
     const uint32_t s = active ? A.pos_seq[gid] : 0u;
@@ -59,19 +59,42 @@ __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
     for (uint32_t k0 = 0; k0 < A.K; k0 += PGM_CS_KC) {
         const uint32_t kc = min((uint32_t)PGM_CS_KC, A.K - k0);
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < kc * tab; t += blockDim.x) {
-            const uint32_t e = t % 22u, cc = t / 22u;   // cc = profile-in-chunk * ncols + column
-            s_lp[t] = e < 21u ? A.lprofiles[(size_t)k0 * gtab + (size_t)cc * 21u + e] : 0.0;
+        {
+            typedef double pgm_d2 __attribute__((ext_vector_type(2)));
+            const pgm_d2 *src = (const pgm_d2 *)(A.lprofiles + (size_t)k0 * rec);
+            pgm_d2 *dst = (pgm_d2 *)cs_lds;
+            for (uint32_t t = threadIdx.x; t < kc * rec / 2u; t += blockDim.x) dst[t] = src[t];
         }
-        for (uint32_t t = threadIdx.x; t < kc * 20u; t += blockDim.x) s_ce[t] = A.centre[(size_t)k0 * 20 + t];
-        if (threadIdx.x < kc) s_pr[threadIdx.x] = A.priors[k0 + threadIdx.x];
         __syncthreads();
-        for (uint32_t kk = 0; kk < kc; ++kk) {
-            const double *lp = s_lp + kk * tab;
-            double pk = s_pr[kk];
+        // PGM_CS_U profiles at a time: their window sums and exponentials are independent chains (the accumulation below
+        // stays in k order), which is what keeps a wavefront's issue slots filled
+        uint32_t kk = 0;
+        for (; kk + PGM_CS_U <= kc; kk += PGM_CS_U) {
+            const double *lp0 = cs_lds + kk * rec;
+            double pk[PGM_CS_U], e[PGM_CS_U];
+#pragma unroll
+            for (int u = 0; u < PGM_CS_U; ++u) pk[u] = lp0[u * rec + tab + 20u];
+            for (int c = 0; c < (int)A.ncols; ++c) {
+                const uint32_t w = woff[c];
+#pragma unroll
+                for (int u = 0; u < PGM_CS_U; ++u) pk[u] = __dadd_rn(pk[u], lp0[u * rec + w]);
+            }
+#pragma unroll
+            for (int u = 0; u < PGM_CS_U; ++u) e[u] = exp(pk[u]);
+#pragma unroll
+            for (int a = 0; a < 20; ++a) {
+                double v = acc[a];
+#pragma unroll
+                for (int u = 0; u < PGM_CS_U; ++u) v = __dadd_rn(v, __dmul_rn(lp0[u * rec + tab + a], e[u]));
+                acc[a] = v;
+            }
+        }
+        for (; kk < kc; ++kk) {
+            const double *lp = cs_lds + kk * rec;
+            double pk = lp[tab + 20u];
             for (int c = 0; c < (int)A.ncols; ++c) pk = __dadd_rn(pk, lp[woff[c]]);
             const double e = exp(pk);
-            const double *ce = s_ce + kk * 20;
+            const double *ce = lp + tab;
 #pragma unroll
             for (int a = 0; a < 20; ++a) acc[a] = __dadd_rn(acc[a], __dmul_rn(ce[a], e));
         }
