@@ -32,8 +32,9 @@ def _score(dim, rng):
 def test_nw_pairs_bit_exact(ctx, dim):
     import oracle_lib
     rng = np.random.default_rng(5 + dim)
-    lens = [0, 1, 2, 63, 64, 65, 127, 128, 129, 200, 333, 700]
-    base = rng.integers(0, dim, 800)
+    # the kernel sweeps bands of 512 rows (8 rows per lane) and stores 2 steps per direction word: lengths around those edges
+    lens = [0, 1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 200, 333, 511, 512, 513, 700, 1030]
+    base = rng.integers(0, dim, 1100)
     seqs = []
     for L in lens:   # related sequences so that the traceback has matches, gaps and mismatches
         s = base[:L].copy()
