@@ -48,7 +48,11 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
     extern __shared__ int nw_score[];  // (D+1)^2
     const int sd = (int)A.dim + 1;
-    for (int i = threadIdx.x; i < sd * sd; i += WAVES * 64) nw_score[i] = A.score[i];
+    // The kernel carries Wg = W + gap_open, Xe = X + gap_extend and Ye = Y + gap_extend instead of W, X, Y (every use of a
+    // neighbour's W in a gap term needs W + gap_open, every use of X / Y needs + gap_extend; W + gap_open feeds two
+    // terms), so the diagonal term is Wg(y-1,x-1) + (score - gap_open): the table holds score - gap_open.  Integer
+    // arithmetic: the values of W, X, Y are the same as with the plain recurrence.
+    for (int i = threadIdx.x; i < sd * sd; i += WAVES * 64) nw_score[i] = A.score[i] - A.gap_open;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const size_t slot = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -85,15 +89,15 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
             // lane l owns the R consecutive rows y0 + r, y0 = BR b + R l + 1: only row 0 takes its upper neighbours from
             // the lane above (DPP), the others from the lane's own registers, so one set of shifts serves R cells
             const int y0 = BR * b + R * lane + 1;  // 1..L2
-            int sy[R], W_left[R], X_left[R];
+            int sy[R], W_left[R], X_left[R];              // W_left = Wg(y, x-1), X_left = Xe(y, x-1)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 sy[r] = (y0 + r <= L2) ? (int)s2[y0 + r - 1] : 0;
-                W_left[r] = go + (y0 + r - 1) * ge;   // W(y,0) = Y(y,0)
-                X_left[r] = MINF;                     // X(y,0)
+                W_left[r] = go + (y0 + r - 1) * ge + go;   // W(y,0) = Y(y,0)
+                X_left[r] = MINF + ge;                     // X(y,0)
             }
-            int W_diag0 = (y0 == 1) ? 0 : go + (y0 - 2) * ge;   // W(y0-1,0)
-            int W_o = MINF, Y_o = MINF, sx_o = 0;               // the last row's outputs, consumed by the lane below
+            int W_diag0 = ((y0 == 1) ? 0 : go + (y0 - 2) * ge) + go;   // W(y0-1,0)
+            int W_o = MINF, Y_o = MINF, sx_o = 0;               // the last row's outputs (Wg, Ye), consumed by the lane below
             uint32_t word = 0;
             for (int t0 = 0; t0 < tsteps; t0 += 64) {
                 // block prefetch for lane 0: seq1 symbols and the row above (columns t0+1 .. t0+64)
@@ -101,8 +105,8 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                 int pf_s = 0, pf_w = MINF, pf_y = MINF;
                 if (xc <= L1) {
                     pf_s = (int)s1[xc - 1];
-                    if (b == 0) { pf_w = go + (xc - 1) * ge; pf_y = MINF; }
-                    else { const int2 v = brow[xc]; pf_w = v.x; pf_y = v.y; }
+                    if (b == 0) { pf_w = go + (xc - 1) * ge + go; pf_y = MINF + ge; }   // (Wg, Ye) of row 0
+                    else { const int2 v = brow[xc]; pf_w = v.x; pf_y = v.y; }          // (Wg, Ye) of the band above's last row
                 }
                 const int tend = min(64, tsteps - t0);
                 for (int i = 0; i < tend; ++i) {
@@ -121,16 +125,16 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                     int Wn[R], Xn[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        const int dc = W_dg + nw_score[sy[r] + so];   // scoring_matrix(s2(y), s1(x))
-                        const int Xv = max(X_left[r] + ge, W_left[r] + go);
-                        const int Yv = max(Y_up + ge, W_up + go);
+                        const int dc = W_dg + nw_score[sy[r] + so];   // W(y-1,x-1) + scoring_matrix(s2(y), s1(x))
+                        const int Xv = max(X_left[r], W_left[r]);
+                        const int Yv = max(Y_up, W_up);
                         const int xy = max(Xv, Yv);
                         const int Wv = max(xy, dc);
                         dbits |= ((dc >= xy) ? 0u : (Xv >= Yv ? 1u : 2u)) << (2 * r);
                         // the next row of this lane: the row above it is this one (same column: just computed; previous
                         // column: W_left before the update)
-                        W_dg = W_left[r]; W_up = Wv; Y_up = Yv;
-                        Wn[r] = Wv; Xn[r] = Xv;
+                        W_dg = W_left[r]; W_up = Wv + go; Y_up = Yv + ge;
+                        Wn[r] = W_up; Xn[r] = Xv + ge;
                     }
                     word |= dbits << ((t % SPW) * 2 * R);
                     if ((t % SPW) == SPW - 1 || t == tsteps - 1) {
