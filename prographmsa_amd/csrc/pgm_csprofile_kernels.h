@@ -32,8 +32,8 @@ struct PgmCsArgs {
 // profile — ncols window columns of 22 entries (the 22nd holds 0.0 for positions outside the sequence, which the
 // reference skips: pk + 0.0 == pk, so the sum is the reference's without a branch per column), then the 20 centre
 // values, the prior and a pad — so that staging a chunk is a straight 16-byte copy.
-#define PGM_CS_KC 8
-#define PGM_CS_U 2    // profiles evaluated together (independent chains); divides PGM_CS_KC
+#define PGM_CS_KC 16
+#define PGM_CS_U 4    // profiles evaluated together (independent chains); divides PGM_CS_KC
 __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
     extern __shared__ double cs_lds[];   // [KC] records
     const uint32_t tab = A.ncols * 22u, rec = tab + 22u;
@@ -71,9 +71,13 @@ __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
         uint32_t kk = 0;
         for (; kk + PGM_CS_U <= kc; kk += PGM_CS_U) {
             const double *lp0 = cs_lds + kk * rec;
+            // the prior and the 20 centre values are the same for every lane: read them through the scalar cache (constant
+            // address space) instead of LDS broadcasts
+            const __attribute__((address_space(4))) double *cg =
+                (const __attribute__((address_space(4))) double *)(uintptr_t)(A.lprofiles + (size_t)(k0 + kk) * rec + tab);
             double pk[PGM_CS_U], e[PGM_CS_U];
 #pragma unroll
-            for (int u = 0; u < PGM_CS_U; ++u) pk[u] = lp0[u * rec + tab + 20u];
+            for (int u = 0; u < PGM_CS_U; ++u) pk[u] = cg[u * rec + 20u];
             for (int c = 0; c < (int)A.ncols; ++c) {
                 const uint32_t w = woff[c];
 #pragma unroll
@@ -85,7 +89,7 @@ __global__ void __launch_bounds__(256) pgm_csprofile_kernel(PgmCsArgs A) {
             for (int a = 0; a < 20; ++a) {
                 double v = acc[a];
 #pragma unroll
-                for (int u = 0; u < PGM_CS_U; ++u) v = __dadd_rn(v, __dmul_rn(lp0[u * rec + tab + a], e[u]));
+                for (int u = 0; u < PGM_CS_U; ++u) v = __dadd_rn(v, __dmul_rn(cg[u * rec + a], e[u]));
                 acc[a] = v;
             }
         }
