@@ -117,7 +117,7 @@ def main():
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_v21_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1_v22_pmc.json")
     if headline and os.path.exists(pmc_path):
         pmc_all = json.load(open(pmc_path))
         pmc = next((v for k, v in pmc_all.items() if k.startswith("pgm_fill_kernel")), {})
@@ -125,7 +125,7 @@ def main():
             traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                "traffic_source": "profiles/r1_v21_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
+                "traffic_source": "profiles/r1_v22_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
                 "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4)},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
 
