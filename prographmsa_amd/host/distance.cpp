@@ -278,8 +278,69 @@ PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
     return tree;
 }
 
-PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf) {
+// ---- distances induced by an alignment (DistanceFactoryPrealigned.h:34-90) -----------------------------------------
+// Pair counts over the columns where both rows have a residue (only residues with value() in 0..19, for every alphabet:
+// the reference's literal 20), one gap per opening of a run in which exactly one of the two rows has a residue.
+DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std::string, sequence_t> &aligned,
+                                                            const std::vector<std::string> &order) {
+    const uint32_t n = (uint32_t)order.size(), D = (uint32_t)alphabet.DIM;
+    DistanceMatrix distances((int)n);
+    std::vector<const sequence_t *> rows(n);
+    for (uint32_t i = 0; i < n; ++i) rows[i] = &aligned.at(order[i]);
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = i + 1; j < n; ++j) pairs.push_back({i, j});
+    Backend &be = default_backend();
+    auto t1 = std::chrono::steady_clock::now();
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
+    nt = std::max(1u, std::min(nt, 16u));
+    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, pairs.size()));
+    auto work = [&](unsigned t) {
+        std::vector<int32_t> counts((size_t)D * D);
+        for (size_t p = t; p < pairs.size(); p += nt) {
+            const sequence_t &s1 = *rows[pairs[p].first], &s2 = *rows[pairs[p].second];
+            if (s1.size() != s2.size()) error("prealigned distances: rows of different length");
+            std::fill(counts.begin(), counts.end(), 0);
+            index_t gaps = 0;
+            bool open1 = false, open2 = false;
+            for (size_t k = 0; k < s1.size(); ++k) {
+                const bool g1 = alphabet.isGap(s1[k]), g2 = alphabet.isGap(s2[k]);
+                if (!g1 && !g2) {
+                    const int c1 = alphabet.value(s1[k]), c2 = alphabet.value(s2[k]);
+                    if (c1 >= 0 && c1 < 20 && c2 >= 0 && c2 < 20) ++counts[(size_t)c1 + (size_t)D * c2];
+                    open1 = false; open2 = false;
+                } else if (g1 && g2) {
+                    // skip
+                } else if (!g1 && !open1) {
+                    ++gaps; open1 = true; open2 = false;
+                } else if (!g2 && !open2) {
+                    ++gaps; open1 = false; open2 = true;
+                }
+            }
+            const distvar_t dv = computeDistance(counts, gaps, ((double)s1.size() + (double)s2.size()) / 2.0);
+            distances.D(pairs[p].first, pairs[p].second) = distances.D(pairs[p].second, pairs[p].first) = dv.dist;
+            distances.V(pairs[p].first, pairs[p].second) = distances.V(pairs[p].second, pairs[p].first) = dv.var;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    return distances;
+}
+
+PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf, bool prealigned) {
     if (seqs.size() < 2) error("cannot construct tree from < 2 sequences");
+    if (prealigned) {
+        std::vector<std::string> order;
+        for (const auto &kv : seqs) order.push_back(kv.first);
+        DistanceFactoryPrealigned df(a, mf);
+        DistanceMatrix dist = df.computePwDistances(seqs, order);
+        for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
+        return midpointRoot(buildNJTree(order, dist));
+    }
     if (!cmdlineopts.nwdist_flag)
         error("initial guide tree: only -a/--nwdist (DistanceFactoryAlign) is built here; pass --tree or -a");
     std::vector<std::string> order;

@@ -49,11 +49,19 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         tree = TreeNJ(a, seqs2, model_factory.get());
     }
     double t_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (cmdlineopts.iters != 0)
-        error("guide-tree re-estimation (-i > 0) needs DistanceFactoryPrealigned, which is outside this build's scope; use -i 0 or --tree");
-
-    ProgressiveAlignmentResult result;
+    ProgressiveAlignmentResult result, old_result;
     t0 = std::chrono::steady_clock::now();
+    // further rounds of alignment followed by estimation of an improved tree from the induced pairwise distances
+    // (main.cpp:404-430; the default is two such rounds when no tree is given)
+    for (int i = 0; i < cmdlineopts.iters; ++i) {
+        result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
+        for (auto it = result.aligned_sequences.begin(); it != result.aligned_sequences.end();)   // ancestral sequences
+            if (!it->first.empty() && it->first[0] == '(') it = result.aligned_sequences.erase(it); else ++it;
+        if (i > 0 && result.aligned_sequences == old_result.aligned_sequences) break;   // converged
+        delete tree;
+        tree = TreeNJ(a, result.aligned_sequences, model_factory.get(), true);
+        old_result = result;
+    }
     if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
     double t_prog = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     out_tree = tree;
@@ -119,7 +127,7 @@ int main(int argc, char **argv) {
             if (!cutdist_set) cmdlineopts.cutoff_dist = 5.0;
         }
         // main.cpp:243-246; this build also cannot iterate (see doAlign), so -a/-T runs behave as `-i 0`
-        if (!iters_set && (!cmdlineopts.tree_file.empty() || cmdlineopts.onlytree_flag)) cmdlineopts.iters = 0;
+        if (!iters_set && !cmdlineopts.tree_file.empty()) cmdlineopts.iters = 0;   // do not iterate when a guide tree is provided (main.cpp:243-246)
         if (!dump.empty()) set_job_dump(dump);
 
         std::vector<std::string> input_order;

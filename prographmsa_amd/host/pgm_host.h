@@ -325,8 +325,16 @@ public:
 private:
     std::vector<int32_t> scoring_matrix_;   // (DIM+1)^2 column-major
 };
+class DistanceFactoryPrealigned : public DistanceFactoryML {   // DistanceFactoryPrealigned.h:34-90
+public:
+    DistanceFactoryPrealigned(const Alphabet &a, const ModelFactory *mf) : DistanceFactoryML(a, mf) {}
+    DistanceMatrix computePwDistances(const std::map<std::string, sequence_t> &aligned,
+                                      const std::vector<std::string> &order);
+};
 PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist);   // TreeNJ.cpp:132-281 (no topology plan)
-PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf);  // TreeNJ.h:27-59, -a only
+// TreeNJ.h:27-59: distances from an all-pairs alignment (-a, prealigned == false) or induced by an existing alignment
+// (prealigned == true, the guide-tree re-estimation of main.cpp:404-430)
+PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf, bool prealigned = false);
 
 std::string data_dir();   // directory holding wag.qmat etc.
 

@@ -113,6 +113,10 @@ def main():
     w("c1.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c1.fa"]))
     w("c1.nw_p.tree", run(["-a", "-T", "-i", "0", "c1.fa"]))
     w("c2.nw_ml.tree", run(["-a", "-m", "-T", "-i", "0", "c2.fa"]))
+    # the reference's default flow from sequences alone: all-pairs guide tree, then two rounds of progressive alignment +
+    # guide-tree re-estimation from the induced distances (DistanceFactoryPrealigned), then the final alignment
+    w("c1.a_iter.out.fa", run(["--fasta", "-a", "c1.fa"]))
+    w("c1.a_iter.tree", run(["-a", "-T", "c1.fa"]))
     nw_trees()
     # context-specific profiles: small synthetic library (K=50), 8x120 family
     w("K50.lib", gen.genlib(50, 7))
@@ -128,6 +132,8 @@ def main():
     # the 64 x 400 family with context-specific profiles and with --mldist, md5 only
     md5["c2.cs.out.fa"] = hashlib.md5(run(["--fasta", "--tree", "c2.tree", "--cs_profile", "K50.lib", "c2.fa"]).encode()).hexdigest()
     md5["c2.m.out.fa"] = hashlib.md5(run(["--fasta", "-m", "--tree", "c2.tree", "c2.fa"]).encode()).hexdigest()
+    md5["c2.a_iter.out.fa"] = hashlib.md5(run(["--fasta", "-a", "c2.fa"]).encode()).hexdigest()
+    md5["c2.a_iter.tree"] = hashlib.md5(run(["-a", "-T", "c2.fa"]).encode()).hexdigest()
     # larger codon families, md5 only (the FASTA is regenerated by tests/gen.py): 40 x 330 and 64 x 500 codons
     for name, fam in (("cd3", gen.gen_codon(40, 330, 23, sub=0.05, indel=0.008)), ("cd4", gen.gen_codon(64, 500, 24, sub=0.04, indel=0.005))):
         fa = gen.fasta(fam)

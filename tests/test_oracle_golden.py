@@ -68,6 +68,18 @@ def test_nw_guide_trees_pdist(oracle_build, tmp_path):
         assert run_oracle(oracle_build, ["-a", "-T", "-i", "0", str(tmp_path / "t.fa")]) == c["tree"], c
 
 
+def test_default_flow_with_tree_reestimation(oracle_build):
+    """`--fasta -a` / `-a -T` with the default two rounds of guide-tree re-estimation (main.cpp:404-430,
+    DistanceFactoryPrealigned): byte-identical FASTA and newick for 8 x 120, md5 for 64 x 400."""
+    c1 = os.path.join(GOLD, "c1.fa")
+    assert run_oracle(oracle_build, ["--fasta", "-a", c1]) == gold("c1.a_iter.out.fa")
+    assert run_oracle(oracle_build, ["-a", "-T", c1]) == gold("c1.a_iter.tree")
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    c2 = os.path.join(GOLD, "c2.fa")
+    assert hashlib.md5(run_oracle(oracle_build, ["--fasta", "-a", c2]).encode()).hexdigest() == md5["c2.a_iter.out.fa"]
+    assert hashlib.md5(run_oracle(oracle_build, ["-a", "-T", c2]).encode()).hexdigest() == md5["c2.a_iter.tree"]
+
+
 def test_nw_guide_tree_c2(oracle_build):
     assert run_oracle(oracle_build, ["-a", "-m", "-T", "-i", "0", os.path.join(GOLD, "c2.fa")]) == gold("c2.nw_ml.tree")
 
