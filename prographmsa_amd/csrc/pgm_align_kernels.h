@@ -156,9 +156,9 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 // Emission kernel (GraphAlign.h:145-163 precomputeScores, fused with ls_log_add): S for every cell, written
 // in the skewed (band, step, lane) order in which the fill kernel consumes it.  No dependencies between
 // cells, so this part of the reference's per-cell work runs at full occupancy, off the DP's critical path.
-// grid = (ceil(nblk / 4), ceil(nb / 4), njobs); block = 192 threads: thread T owns row T % 48 of band 4 blockIdx.y + T / 48
-// (no idle replay lanes here) and computes its cells of PGM_EM_TB = 4 step blocks (columns t - l, l = 16 + T % 48).
-// The 79 columns of T = M^T g2 the workgroup touches are staged in LDS as overlapping column PAIRS
+// grid = (ceil(nblk / 4), ceil(nb / 4), njobs); block = 256 threads: thread T owns row T % 64 of band 4 blockIdx.y + T / 64
+// and computes its cells of PGM_EM_TB = 4 step blocks (columns t - l, l = T % 64).
+// The 95 columns of T = M^T g2 the workgroup touches are staged in LDS as overlapping column PAIRS
 // {T[c][k], T[c+1][k]}: two consecutive cells of a row are then one packed multiply and one packed add per k
 // (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, the same sequential mul-then-add order as the scalar code).
 // Global-address-space accesses: pointers taken from a PgmJob in memory are generic, and generic (flat) loads / stores
@@ -168,10 +168,10 @@ typedef float pgm_v4f __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T pgm_gld(const T *p) { return *(const PGM_GLOBAL T *)(uintptr_t)p; }   // scalar global load
 #define PGM_EM_TB 4   // step blocks per emission workgroup
 template <int DP>
-__global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
+__global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
     typedef float pgm_v2f __attribute__((ext_vector_type(2)));
     constexpr int NT = DP / 4;
-    constexpr int COLS = 64 + PGM_EM_TB * PGM_BLOCK - PGM_HALO - 1;   // columns [t0 - 63, t0 + PGM_EM_TB * PGM_BLOCK - 1 - 16]
+    constexpr int COLS = 64 + PGM_EM_TB * PGM_BLOCK - PGM_HALO - 1;   // columns [t0 - 63, t0 + PGM_EM_TB * PGM_BLOCK - 1 - PGM_HALO]
     __shared__ pgm_v2f tp[(COLS + 1) * DP];      // tp[c * DP + k] = {T[c][k], T[c+1][k]} (row COLS is scratch)
     __shared__ float bq[COLS];
     const PgmJob &J = jobs[blockIdx.z];
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__
     // one float4 load per (column, 4 k): the value T[c][k] is the low half of pair c and the high half of pair c - 1
     const float4 *t2q = (const float4 *)J.t2;
     float *tpf = (float *)tp;
-    for (int i = threadIdx.x; i < (COLS + 1) * NT; i += 192) {
+    for (int i = threadIdx.x; i < (COLS + 1) * NT; i += 4 * PGM_ROWS) {
         const int ci = i / NT, q = i % NT, c = cbase + ci;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c >= 0 && c <= (int)J.ncol) v = t2q[(size_t)NT * c + q];
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(192) pgm_emission_skew_kernel(const PgmJob *__
             if (ci > 0) tpf[2 * ((ci - 1) * DP + k) + 1] = vv[u];
         }
     }
-    for (int i = threadIdx.x; i < COLS; i += 192) {
+    for (int i = threadIdx.x; i < COLS; i += 4 * PGM_ROWS) {
         const int col = cbase + i;
         bq[i] = (col >= 0 && col <= (int)J.ncol) ? J.b2[col] : 0.f;
     }
@@ -255,28 +255,25 @@ __device__ __forceinline__ int pgm_wave_max8(uint32_t v) {
 // with L1-bypassing loads; the hand-off itself is the progress counter below (MI355X guide, Guideline 16 R1).
 // The cell store is a raw buffer store with aux = 16 (sc1, write-through to device scope): unlike an inline-asm
 // store it is counted by hipcc's s_waitcnt bookkeeping, so the counted waits on the prefetch loads stay exact.
-// The descriptor covers one band (tsteps * 64 cells); the step offset goes in the scalar offset, the lane in voffset.
+// The descriptor covers one band (tsteps * 64 cells); step and lane both go into the VGPR offset (see below).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pgm_band_rsrc(float4 *base, uint32_t bytes) {
     const uint64_t p = (uint64_t)base;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-template <int MODE = 0>
-__device__ __forceinline__ void pgm_store_cell(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, float Mv, float Xv, float Wv, float Yv) {
-    typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
-    pgm_v4u v;
-    v.x = __float_as_uint(Mv); v.y = __float_as_uint(Xv); v.z = __float_as_uint(Wv); v.w = __float_as_uint(Yv);
-    if (MODE == 1) return;                                                    // timing experiments only
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (uint32_t)lane * 16u, __builtin_amdgcn_readfirstlane(t) * 1024u, MODE == 2 ? 0 : 16);
-}
 // Same store issued by every lane: lanes with `on == false` get an offset beyond the descriptor's num_records and the
 // buffer range check drops them.  No branch around the store, so every step issues exactly one vector memory
 // instruction, which is what lets the compiler turn the waits on the block prefetch into counted waits (vmcnt(8)).
+// The step offset goes into the VGPR offset, NOT into the scalar offset: a 128-bit buffer store reads its data registers
+// over several cycles, and a VALU instruction right behind it that overwrites one of them needs wait states.  hipcc
+// (ROCm 7.2) inserts them only for stores WITHOUT an SGPR soffset (it assumes the hazard does not exist with one); on
+// gfx950 it does: with `soffset = t * 1024` the M word of lanes 12-15 of every 16 was overwritten by the next step's
+// column index whenever the register allocator reused the register (found with the 64-row re-lay of round 2).
 __device__ __forceinline__ void pgm_store_cell_masked(__amdgpu_buffer_rsrc_t rsrc, uint32_t t, int lane, bool on, float Mv, float Xv, float Wv, float Yv) {
     typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
     pgm_v4u v;
     v.x = __float_as_uint(Mv); v.y = __float_as_uint(Xv); v.z = __float_as_uint(Wv); v.w = __float_as_uint(Yv);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, on ? (uint32_t)lane * 16u : 0x80000000u, __builtin_amdgcn_readfirstlane(t) * 1024u, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (on ? (uint32_t)lane * 16u : 0x80000000u) + t * 1024u, 0, 16);
 }
 // Loads through global-address-space pointers (global_load, returned in issue order and counted by vmcnt) instead of
 // generic ones (flat_load, which the compiler can only wait for with vmcnt(0)).
@@ -844,93 +841,343 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // ---------------------------------------------------------------------------------------------
 // Fill kernel (GraphAlign.h:212-260 incl. the border initialisation as row/column 0).
 //
-// Work unit = one BAND of one job: 48 consecutive rows of graph 1 against all columns of graph 2.  The bands of all
-// jobs of the batch sit in one list ordered by longest remaining path first (host side); a persistent grid of
-// workers (256-thread workgroups) takes them through an atomic ticket counter.  Band b of a job is always listed
-// after band b-1, so the worker it waits for already holds its band and is running: hand-offs cannot deadlock.
+// Work unit = one BAND of one job: 64 consecutive rows of graph 1 against all columns of graph 2, swept by ONE
+// wavefront on its own (no helper wavefronts, no barrier inside a sweep).  Lane l owns row y = 64 b + l and at step t
+// computes column x = t - l: the cells of one step are independent of each other, every predecessor cell was produced
+// by a lower or the same lane at an earlier step.  An item of the work list is up to four consecutive bands of one
+// job, one per wavefront of the worker (256-thread workgroup) that takes it; all bands of all jobs of the batch sit in
+// one list ordered by the host (longest remaining path first), a persistent grid of workers takes them through an
+// atomic ticket.  Band b of a job is always listed after band b-1, so the wavefront it waits for is already running.
 //
-// A worker is four wavefronts.  Wavefront 0 ("main") owns the band's dependency chain: lanes 16..63 own rows
-// y = 48 b + l - 16 and at step t compute column x = t - l, so the three chain neighbours (y-1,x-1), (y-1,x), (y,x-1)
-// are in registers of lane l-1 (one DPP shift) or of the lane itself.  Lanes 0..15 do not compute: they REPLAY the
-// last 16 rows of band b-1 (read back from the cell storage, one contiguous 256 B run per step, staged through LDS
-// a block ahead), so that every predecessor row within 16 rows of a lane lives in a lower lane of the same wavefront.
-// Wavefronts 1..3 ("helpers") evaluate the skip-edge terms of merged graphs; for a chain-only job they skip the band
-// and the main wavefront runs alone.  Every skip-edge term of step t needs history only up to step t-2 (an extra
-// predecessor is at least 2 nodes back), so the helpers work on step t+1 while the main wavefront does step t; one
-// hardware barrier per step ("tick") keeps the four in lock step.
-//   helper 1: column extras (X terms, M terms with the chain row), one row per lane, loop to the wavefront's max count
-//   helper 2: row extras: one (row, extra) ENTRY per lane: Y term, M term with the chain column, pairs with column extras 0..2
-//   helper 3: the same entries: pairs with column extras 3..6
-//
-// Per-worker LDS:
-//   ring  : predecessor summary (PgmNodeInfo) of the last 80 columns, stored two 8-column blocks ahead
-//   hW/hY/hX : W, Y, X of all 64 lanes for the last 32 steps.  A skip-edge predecessor pair (y-dy, x-dx) was produced
-//           by lane l-dy exactly dy+dx steps ago, so skip edges are served from this history without touching HBM.
-//   rep   : replay values {W,Y} of the current block;  sblk : emission scores of the current and the next block
-//   res1/resA : partial maxima of the helpers for the current and the next step
-// Nodes with a predecessor more than 31 nodes back or with more than 7 extra predecessors (far tandem-repeat
-// edges, pathological graphs) fall back to reading the cell storage (HBM/L2) for all their extras.
-// Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b
-// that are complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
-// CYCLES = true: instrumented build for tools/probe_cyc.py (cycle counters per band into map1, no traceback)
-template <bool CYCLES>
-__global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
-                                                      int *__restrict__ sync, unsigned long long *__restrict__ trace) {
-    int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
-    constexpr int NQ = 4;
-    constexpr int R = PGM_RING, H = PGM_HIST, HW = PGM_HISTW, HR = PGM_HALO, RC = PGM_ROWS, BL = PGM_BLOCK;
-    constexpr int PFQ = (BL * NQ + 63) / 64;
-    // LDS of the band sweep; the traceback a worker runs after a job's last band reuses the same memory (PgmTbLds)
-    struct FillLds {
-        float4 ring[R * NQ];
-        float hW[HW * 64];
-        float hY[H * 64];
-        float hX[H * 64];
-        float2 rep[BL * HR];
-        float sblk[2 * BL * 64];
-        float res1[2 * 2 * 64];     // [step & 1][M, X][lane]: partial maxima of helper 1 (plain stores)
-        float resA[2 * 2 * 64];     // [step & 1][M, Y][lane]: partial maxima of helpers 2 and 3 (LDS float-max atomics)
-        uint32_t el_a[PGM_ENT];     // row-extra entries of the band: distance << 8 | owner lane
-        float el_c[PGM_ENT];        //                                 edge cost
-        uint32_t ovf[64];           // rows whose entries did not fit (they take the generic path)
-        int el_cnt;
-        int lds_abort;
-    };
-    // chain-only jobs (no skip edges, no helpers): the four wavefronts sweep four consecutive bands of the job, each with
-    // its own ring / replay tile / score buffers
-    struct ChainLds {
-        float4 ring[R * NQ];
-        float2 rep[BL * HR];
-        float sblk[2 * BL * 64];
-    };
-    __shared__ __attribute__((aligned(16))) union { FillLds f; ChainLds c[4]; PgmTbLds t; } L;
-    __shared__ int item_lds, tb_go;
-    float (&hW)[HW * 64] = L.f.hW;
-    float (&hY)[H * 64] = L.f.hY;
-    float (&hX)[H * 64] = L.f.hX;
-    float (&res1)[2 * 2 * 64] = L.f.res1;
-    float (&resA)[2 * 2 * 64] = L.f.resA;
-    uint32_t (&el_a)[PGM_ENT] = L.f.el_a;
-    float (&el_c)[PGM_ENT] = L.f.el_c;
-    uint32_t (&ovf)[64] = L.f.ovf;
-    int &el_cnt = L.f.el_cnt;
-    int &lds_abort = L.f.lds_abort;
+// Predecessors of a cell (y, x) are pairs (y - dy, x - dx) of a predecessor of node y and one of node x.
+//   NEAR (dy, dx in 1..3; 90 % of all skip edges of a merged graph span 2 or 3 nodes): a systolic register window.
+//       W(y-1, x) is what lane l-1 produced in the previous step (one DPP wave_shr:1); W(y-2, x) is what lane l-1
+//       received as ITS upper neighbour one step ago, W(y-3, x) what it received as its second one: three DPP shifts
+//       per step keep, in every lane, the last four columns of the three rows above (u1W, u2W, u3W), the lane's own
+//       last three columns (ow, ox) and Y of the three rows above.  All 9 + 3 + 3 near terms are then evaluated
+//       unconditionally with the edge costs {cc, c2, c3} of the row (registers) and of the column (one ds_read_b128
+//       from a ring of column summaries); an absent edge has cost +inf and contributes -inf.  No LDS round trip, no
+//       divergence, no loop.
+//   FAR (any other edge, up to PGM_KF per node, distance <= PGM_DCAP): served from an LDS history of the band's
+//       W, Y, X of the last hD steps (hW[step][16 + lane]): (y - dy, x - dx) was produced by lane l - dy at step
+//       t - dy - dx.  The far code runs only in steps in which some lane has a far edge (wave-uniform branch).
+//   Rows above the band: the last 16 rows of band b-1 are "virtual lanes" -16..-1 of the history (read back from the
+//       cell storage a block ahead: because of the skew they are ONE contiguous 256 B run per step); lane 0's three
+//       upper neighbours are injected from there (the DPP's `old` operand).
+//   GENERIC (more than PGM_KF far edges, farther than PGM_DCAP or above the virtual lanes): the node's edges are read
+//       from the cell storage through the CSR lists (device-scope loads), as rare as pathological graphs are.
+// Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b that are
+// complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
+template <bool NEAR>
+__device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *abort_flag, bool &aborted,
+                                               const uint32_t spin_limit, const bool stall, unsigned long long *wait_acc) {
+    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF;
+    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
+    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
+    const uint32_t D = J.hD, Dm = D - 1u, DX = J.hDX, DXm = DX - 1u;
+    const bool has_far = NEAR && J.has_far != 0;
+    // LDS of this sweep: W / Y history [D][80] (columns 0..15: virtual lanes), X history [DX][64], column summaries [128][3]
+    float *hW = (float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
+    float4 *ring3 = (float4 *)(hX + DX * 64u);
+    const uint32_t y = 64u * b + (uint32_t)lane;
+    const bool rowvalid = y + 1 < n1;
+    const uint32_t yc = rowvalid ? y : 0u;
+    const float4 *niq = (const float4 *)(J.ni1 + yc);
+    const float4 r0 = pgm_gload4(niq), r1 = pgm_gload4(niq + 1), r2 = pgm_gload4(niq + 2);
+    const float ccy = r0.x;
+    const uint32_t fy = rowvalid ? __float_as_uint(r0.w) : 0u;
+    const bool geny = NEAR && ((fy & 8u) != 0 || ((fy & 7u) != 0 && ((fy >> 8) & 255u) > (uint32_t)(lane + VL)));
+    const bool ykill = (fy & 16u) != 0;
+    const float c2y = (NEAR && !geny) ? r0.y : INFINITY, c3y = (NEAR && !geny) ? r0.z : INFINITY;
+    uint32_t fdy[KF];
+    float fcy[KF];
+    {
+        const float dsrc[KF] = {r1.x, r1.y, r1.z, r1.w}, csrc[KF] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            fdy[k] = (NEAR && rowvalid && !geny) ? __float_as_uint(dsrc[k]) : 0u;
+            fcy[k] = (NEAR && rowvalid && !geny) ? csrc[k] : INFINITY;
+        }
+    }
+    const int nfyw = NEAR ? pgm_wave_max8(geny ? 0u : (fy & 7u)) : 0;
+    const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
+    const float gopen_x = (rowvalid && y == 0) ? sg : gi;
+    const bool has_next = (b + 1 < nb), has_prev = (b > 0);
+    float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
+    const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
+    const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;
+    const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
+    const float4 *ni2q = (const float4 *)J.ni2;
+    const uint32_t lb = (uint32_t)(VL + lane);
 
+    for (uint32_t i = (uint32_t)lane; i < D * HS; i += 64u) { hW[i] = PGM_NEG_INF; hY[i] = PGM_NEG_INF; }
+    for (uint32_t i = (uint32_t)lane; i < DX * 64u; i += 64u) hX[i] = PGM_NEG_INF;
+    for (int i = lane; i < NR * 3; i += 64) ring3[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // "column < 0" slots
+
+    // ---- block prefetch (global -> registers a block ahead -> LDS / registers of the block) ------------------------
+    float4 pfq, pfs[BL / 4];
+    float2 pfr[2];
+    const int rq_col = lane / 3, rq_part = lane % 3;   // lanes 0..23: one float4 of the 8 column summaries of a block
+    auto load_ring_block = [&](uint32_t c0) {
+        const uint32_t col = c0 + (uint32_t)rq_col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 3 * BL && col <= ncol) v = pgm_gload4(ni2q + 3u * col + (uint32_t)rq_part);
+        pfq = v;
+    };
+    auto store_ring_block = [&](uint32_t c0) {
+        if (lane < 3 * BL) ring3[((c0 + (uint32_t)rq_col) & (uint32_t)(NR - 1)) * 3u + (uint32_t)rq_part] = pfq;
+    };
+    auto load_s_block = [&](uint32_t s0) {
+        const uint32_t tb = s0 / BL;
+#pragma unroll
+        for (int q = 0; q < BL / 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tb < nblk) v = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
+            pfs[q] = v;
+        }
+    };
+    // virtual lanes of my steps s0 .. s0+7: virtual lane v (= lane v - 16, i.e. row 64 b - 16 + v) at my step s is the cell
+    // lane 48 + v of band b-1 produced at ITS step s + 64 (column s + 16 - v); cells outside the matrix read as -inf
+    auto load_rep_block = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane * 2 + u, s = s0 + e / VL, v = e % VL;
+            const int col = s + (VL - v);
+            float2 val = make_float2(PGM_NEG_INF, PGM_NEG_INF);
+            if (has_prev && col >= 0 && col < (int)ncol) val = pgm_gload_cell_wy(cells_prev + (size_t)(s + 64) * 64u + (uint32_t)(64 - VL + v));
+            pfr[u] = val;
+        }
+    };
+    auto store_rep_block = [&](int s0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane * 2 + u, s = s0 + e / VL, v = e % VL;
+            const uint32_t idx = ((uint32_t)s & Dm) * HS + (uint32_t)v;
+            hW[idx] = pfr[u].x;
+            hY[idx] = pfr[u].y;
+        }
+    };
+    int seen = has_prev ? 0 : 0x7fffffff, pend = 0;
+    auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
+        if (seen != 0x7fffffff && !aborted) {
+            const int need = (int)min(steps_needed, tsteps);
+            uint32_t spins = 0;
+            const unsigned long long w0 = (wait_acc && seen < need) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            while (seen < need) {
+                seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= need) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > spin_limit || __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    aborted = true;
+                    break;
+                }
+            }
+            if (w0) *wait_acc += __builtin_amdgcn_s_memrealtime() - w0;
+        }
+    };
+    // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
+    // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
+    auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
+
+    // prologue: column summaries of blocks 0 and 1 straight in, block 2 in flight; scores of block 0 in registers, block 1
+    // in flight; virtual lanes of the steps before 0 (they reach back min(16, D - 8) steps) and of block 0 in, block 1 in flight
+    float Sc[BL];
+    load_ring_block(0); store_ring_block(0);
+    load_ring_block(BL); store_ring_block(BL);
+    load_s_block(0);
+#pragma unroll
+    for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
+    load_s_block(BL);
+    wait_prev(BL + 64 + BL);
+    if (has_prev) {
+        if (D >= (uint32_t)(VL + BL)) { load_rep_block(-2 * BL); store_rep_block(-2 * BL); }
+        load_rep_block(-BL); store_rep_block(-BL);
+        load_rep_block(0); store_rep_block(0);
+    }
+    load_ring_block(2 * BL);
+    load_rep_block(BL);
+    poll_issue();
+
+    // ---- the sweep ---------------------------------------------------------------------------------------------------
+    float u1W[4], u2W[4], u3W[4], ow[4], ox[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u1W[k] = PGM_NEG_INF; u2W[k] = PGM_NEG_INF; u3W[k] = PGM_NEG_INF; ow[k] = PGM_NEG_INF; ox[k] = PGM_NEG_INF; }
+    float u1Y = PGM_NEG_INF, u2Y = PGM_NEG_INF, u3Y = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
+    for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const uint32_t t = t0 + i;
+            const int xs = (int)t - lane;
+            const bool incol = xs >= 0 && xs < (int)ncol;
+            const bool active = rowvalid && incol;
+            const uint32_t x = (uint32_t)xs;
+            const uint32_t rslot = (x & (uint32_t)(NR - 1)) * 3u;
+            const float4 cn = ring3[rslot];
+            const float ccx = cn.x, c2x = NEAR ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
+            const uint32_t fx = __float_as_uint(cn.w);
+            const bool genx = NEAR && active && (fx & 8u) != 0;
+            const bool xkill = active && (fx & 16u) != 0;
+            const float gopen_y = (xs == 0) ? sg : gi;
+            const float S = Sc[i];
+            // the rows above: lane 0's upper neighbours come from the virtual lanes of the history (all lanes read the same
+            // word, only lane 0 keeps it: `old` operand of the DPP shift)
+            const uint32_t tm1 = ((t - 1u) & Dm) * HS, tm2 = ((t - 2u) & Dm) * HS, tm3 = ((t - 3u) & Dm) * HS;
+            const int s0 = i & 3, sm1 = (i + 3) & 3, sm2 = (i + 2) & 3, sm3 = (i + 1) & 3;
+            if (NEAR) {
+                const float iW3 = hW[tm3 + VL - 3], iY3 = hY[tm3 + VL - 3], iW2 = hW[tm2 + VL - 2], iY2 = hY[tm2 + VL - 2];
+                const float n3W = pgm_dpp_wave_shr1(u2W[sm1], iW3), n2W = pgm_dpp_wave_shr1(u1W[sm1], iW2);
+                const float n3Y = pgm_dpp_wave_shr1(u2Y, iY3), n2Y = pgm_dpp_wave_shr1(u1Y, iY2);
+                u3W[s0] = n3W; u2W[s0] = n2W; u3Y = n3Y; u2Y = n2Y;
+            }
+            {
+                const float iW1 = hW[tm1 + VL - 1], iY1 = hY[tm1 + VL - 1];
+                u1W[s0] = pgm_dpp_wave_shr1(W_o, iW1);
+                u1Y = pgm_dpp_wave_shr1(Y_o, iY1);
+            }
+            auto mterm = [&](float w, float cy, float cx) { return __fsub_rn(__fsub_rn(__fadd_rn(w, S), cy), cx); };
+            auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
+            auto yterm = [&](float yp, float wp, float cy) { return __fsub_rn(fmaxf(__fadd_rn(yp, ge), __fadd_rn(wp, gopen_y)), cy); };
+            float Mv = mterm(u1W[sm1], ccy, ccx);
+            float Xv = xterm(ox[sm1], ow[sm1], ccx);
+            float Yv = yterm(u1Y, u1W[s0], ccy);
+            if (NEAR) {
+                Mv = fmaxf(Mv, fmaxf(mterm(u1W[sm2], ccy, c2x), mterm(u1W[sm3], ccy, c3x)));
+                Mv = fmaxf(Mv, fmaxf(mterm(u2W[sm1], c2y, ccx), fmaxf(mterm(u2W[sm2], c2y, c2x), mterm(u2W[sm3], c2y, c3x))));
+                Mv = fmaxf(Mv, fmaxf(mterm(u3W[sm1], c3y, ccx), fmaxf(mterm(u3W[sm2], c3y, c2x), mterm(u3W[sm3], c3y, c3x))));
+                Xv = fmaxf(Xv, fmaxf(xterm(ox[sm2], ow[sm2], c2x), xterm(ox[sm3], ow[sm3], c3x)));
+                Yv = fmaxf(Yv, fmaxf(yterm(u2Y, u2W[s0], c2y), yterm(u3Y, u3W[s0], c3y)));
+                // ---- far edges: LDS history ----
+                const uint32_t nfx = fx & 7u;
+                if (__builtin_expect(nfyw != 0 || __builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull, 0)) {
+                    const float4 f1 = ring3[rslot + 1u], f2 = ring3[rslot + 2u];
+                    const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w)};
+                    const float fcx[KF] = {f2.x, f2.y, f2.z, f2.w};
+                    const int nfxw = pgm_wave_max8(nfx);
+#pragma unroll
+                    for (int j = 0; j < KF; ++j) {
+                        if (j < nfxw) {
+                            const uint32_t s1 = t - fdx[j];
+                            const float Xh = hX[(s1 & DXm) * 64u + (uint32_t)lane], Wh = hW[(s1 & Dm) * HS + lb];
+                            const float W1 = hW[((s1 - 1u) & Dm) * HS + lb - 1u], W2 = hW[((s1 - 2u) & Dm) * HS + lb - 2u], W3 = hW[((s1 - 3u) & Dm) * HS + lb - 3u];
+                            Xv = fmaxf(Xv, xterm(Xh, Wh, fcx[j]));
+                            Mv = fmaxf(Mv, fmaxf(mterm(W1, ccy, fcx[j]), fmaxf(mterm(W2, c2y, fcx[j]), mterm(W3, c3y, fcx[j]))));
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KF; ++k) {
+                        if (k < nfyw) {
+                            const uint32_t s1 = t - fdy[k], lp = lb - fdy[k];
+                            const float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
+                            const float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                            Yv = fmaxf(Yv, yterm(Yh, Wh, fcy[k]));
+                            Mv = fmaxf(Mv, fmaxf(mterm(W1, fcy[k], ccx), fmaxf(mterm(W2, fcy[k], c2x), mterm(W3, fcy[k], c3x))));
+#pragma unroll
+                            for (int j = 0; j < KF; ++j) {
+                                if (j < nfxw) {
+                                    const float Wp = hW[((s1 - fdx[j]) & Dm) * HS + lp];
+                                    Mv = fmaxf(Mv, mterm(Wp, fcy[k], fcx[j]));
+                                }
+                            }
+                        }
+                    }
+                }
+                // ---- generic nodes: every non-chain predecessor through the CSR lists and the cell storage ----
+                const bool gen = active && (geny || genx);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(gen) != 0ull, 0)) {
+                    if (gen) {
+                        const uint32_t xbx = (uint32_t)pgm_gld(J.xp2 + x), xex = (uint32_t)pgm_gld(J.xp2 + x + 1);
+                        for (uint32_t e = xby; e < xey; ++e) {
+                            const uint32_t yp = pgm_gld(J.xc1 + e);
+                            const float cy = pgm_gld(J.xv1 + e);
+                            const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
+                            Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
+                            if (x > 0) {
+                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x - 1));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
+                            }
+                            for (uint32_t f = xbx; f < xex; ++f) {
+                                const uint32_t xp = pgm_gld(J.xc2 + f);
+                                const float cx = pgm_gld(J.xv2 + f);
+                                const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
+                            }
+                        }
+                        for (uint32_t f = xbx; f < xex; ++f) {
+                            const uint32_t xp = pgm_gld(J.xc2 + f);
+                            const float cx = pgm_gld(J.xv2 + f);
+                            const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
+                            const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
+                            Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
+                            if (y > 0) {
+                                const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, y - 1, xp));
+                                Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), ccy), cx));
+                            }
+                        }
+                    }
+                }
+            }
+            if (ykill) Xv = PGM_NEG_INF;
+            if (xkill) Yv = PGM_NEG_INF;
+            float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
+            if (rowvalid && y == 0 && xs == 0) Wv = s_init;
+            if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
+            pgm_store_cell_masked(cells_rsrc, t, lane, active, Mv, Xv, Wv, Yv);
+            if (has_far) {
+                const uint32_t ho = (t & Dm) * HS + lb;
+                hW[ho] = Wv;
+                hY[ho] = Yv;
+                hX[(t & DXm) * 64u + (uint32_t)lane] = Xv;
+            }
+            W_o = Wv;
+            Y_o = Yv;
+            ow[s0] = Wv;
+            ox[s0] = Xv;
+        }
+        if (has_next && !stall) {
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
+            if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // Stage the next blocks.  This sits at the END of the iteration so that, on every path into it, exactly the BL
+        // cell stores of this block were issued after the prefetch loads consumed here: the compiler then waits for them
+        // with vmcnt(BL) instead of vmcnt(0), i.e. the wavefront never drains the stores it has just issued.
+        const uint32_t t1 = t0 + BL;
+        if (t1 < tsteps) {
+            store_ring_block(t1 + BL);     // one block before use
+#pragma unroll
+            for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
+            store_rep_block((int)t1);
+            load_ring_block(t1 + 2 * BL);
+            load_s_block(t1 + BL);
+            poll_collect();
+            wait_prev(t1 + BL + BL + 64);
+            load_rep_block((int)(t1 + BL));
+            poll_issue();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && !stall) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// NOTRACEBACK = true: timing build for tools (the fill alone, no traceback)
+template <bool NOTRACEBACK>
+__global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
+                                                      int *__restrict__ sync, unsigned long long *__restrict__ trace,
+                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band) {
+    int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
+    // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
+    __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
+    __shared__ int item_lds, tb_go;
+    static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
-    // One hardware barrier per step keeps the four wavefronts in lock step ("tick"): only LDS traffic has to be
-    // complete at the barrier, the cell stores in flight are not waited for (a plain __syncthreads() would drain them).
-    auto tick = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    };
     for (;;) {
         // next item of the list (all four wavefronts take the same one)
         __syncthreads();
         if (threadIdx.x == 0) {
             int it = -1;
-            if (!aborted && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
         }
@@ -945,523 +1192,33 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         // optional timeline (tools/probe_trace.py): per item {worker, start, end of band, end of traceback} in 100 MHz ticks
         if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
         const PgmJob &J = jobs[item.job];
-        // Merged graphs: one band, wavefront 0 sweeps it, wavefronts 1..3 help.  Chain-only jobs ("pack"): item.count <= 4
-        // consecutive bands, wavefront w sweeps band item.band + w on its own (no barriers inside the sweep; the bands
-        // hand over through the cell storage like any two bands).
-        const bool need_help = J.has_extras != 0;
-        const bool pack = !need_help;
-        const uint32_t b = item.band + (pack ? (uint32_t)role : 0u);
+        const uint32_t b = item.band + (uint32_t)role;
         const bool last_band = (item.band + item.count == J.nb);
-        const bool sweeper = pack ? ((uint32_t)role < item.count) : (role == 0);   // this wavefront owns the chain of a band
-        if (!sweeper && !need_help && !last_band) continue;
-        float4 *ring = pack ? L.c[role].ring : L.f.ring;
-        float2 *rep = pack ? L.c[role].rep : L.f.rep;
-        float *sblk = pack ? L.c[role].sblk : L.f.sblk;
-        if (sweeper || need_help) {
-        const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
-        const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
-        const bool comp = lane >= HR;
-        const uint32_t y = RC * b + (uint32_t)(lane - HR);
-        const bool rowvalid = comp && y + 1 < n1;
-        const uint32_t yc = rowvalid ? y : 0u;
-        const PgmNodeInfo niy = J.ni1[yc];
-        const float ccy = niy.cc;
-        const uint32_t fy = rowvalid ? niy.flags : 0u;
-        const uint32_t dymax = (fy >> 8) & 255u;
-        const bool geny = (fy & 8u) != 0 || dymax > (uint32_t)lane;
-        bool geny_m = geny;   // main wavefront: plus the rows whose entries overflowed the list
-        bool no_ent = true;   // main wavefront: the band has no row-extra entries (helpers 2 and 3 contribute nothing)
-        const bool ykill = (fy & 16u) != 0;
-        uint32_t rk8[PGM_KX], lk4[PGM_KX];
-        float cyv[PGM_KX];
-#pragma unroll
-        for (int k = 0; k < PGM_KX; ++k) {
-            rk8[k] = (rowvalid && !geny) ? niy.d[k] : 0u;
-            cyv[k] = (rowvalid && !geny) ? niy.c[k] : INFINITY;
-            lk4[k] = (uint32_t)(lane * 4) - (rk8[k] >> 6);
-        }
-        const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
-        const float gopen_x = (rowvalid && y == 0) ? sg : gi;
-        const bool has_next = (b + 1 < nb);
-        const bool has_prev = (b > 0);
-        float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
-        const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
-        const float4 *cells_prev = J.cells + (size_t)(b - 1) * tsteps * 64u;
-        const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
-        const float4 *ni2q = (const float4 *)J.ni2;
-        int xr = (R - lane) % R;
-
-        // ---- history addressing shared by the helper roles ----------------------------------------------------------
-        const char *hWb = (const char *)hW, *hYb = (const char *)hY, *hXb = (const char *)hX;
-        constexpr uint32_t MW = (uint32_t)(HW - 1) << 8, MH = (uint32_t)(H - 1) << 8;
-        const uint32_t lane4 = (uint32_t)lane * 4u;
-        // The history is read in batches: inside a chunk nothing is conditional (an absent extra has
-        // distance 0 and cost +inf, so its term is -inf whatever the slot holds), which lets all LDS reads of the chunk be
-        // issued back to back instead of one LDS round trip per term.
-        // part 1: column extras j -> X term and the M term with the chain row (source lane l-1)
-        auto cols_chunk = [&](auto j0c, auto j1c, uint32_t t8, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn, float &Xn) {
-            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-            float Wj[J1 - J0], Xj[J1 - J0], W1[J1 - J0];
-#pragma unroll
-            for (int j = J0; j < J1; ++j) {
-                const uint32_t tj8 = t8 - cj8[j];
-                Wj[j - J0] = *(const float *)(hWb + ((tj8 & MW) | lane4));
-                Xj[j - J0] = *(const float *)(hXb + ((tj8 & MH) | lane4));
-                W1[j - J0] = *(const float *)(hWb + (((tj8 - 256u) & MW) | ((lane4 - 4u) & 255u)));
-            }
-#pragma unroll
-            for (int j = J0; j < J1; ++j) {
-                Xn = fmaxf(Xn, __fsub_rn(fmaxf(__fadd_rn(Xj[j - J0], ge), __fadd_rn(Wj[j - J0], gopen_x)), cxv[j]));
-                Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(W1[j - J0], S), ccy), cxv[j]));
-            }
-        };
-        auto part_cols = [&](uint32_t t8, int nxw, const uint32_t (&cj8)[PGM_KX], const float (&cxv)[PGM_KX], float S, float &Mn, float &Xn) {
-            cols_chunk(std::integral_constant<int, 0>(), std::integral_constant<int, 4>(), t8, cj8, cxv, S, Mn, Xn);
-            if (nxw > 4) cols_chunk(std::integral_constant<int, 4>(), std::integral_constant<int, PGM_KX>(), t8, cj8, cxv, S, Mn, Xn);
-        };
-
-        if (sweeper) for (int i = lane; i < R * NQ; i += 64) ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // "column < 0" slots
-        if (role == 0 && need_help) {
-            for (int i = lane; i < HW * 64; i += 64) hW[i] = PGM_NEG_INF;
-            for (int i = lane; i < H * 64; i += 64) { hY[i] = PGM_NEG_INF; hX[i] = PGM_NEG_INF; }
-            for (int i = lane; i < 2 * 2 * 64; i += 64) resA[i] = PGM_NEG_INF;
-            if (lane == 0) {
-                lds_abort = 0;
-            }
-        } else if (role == 2) {
-            // Row-extra entry list of this band (order irrelevant): each row appends its extras at a position taken from
-            // an LDS counter.  LDS operations of one wavefront execute in order, so the reset below precedes the adds.
-            if (lane == 0) el_cnt = 0;
-            const uint32_t cnt = (rowvalid && !geny) ? (fy & 7u) : 0u;
-            uint32_t base = 0;
-            if (cnt) base = (uint32_t)__hip_atomic_fetch_add(&el_cnt, (int)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool ov = cnt != 0 && base + cnt > (uint32_t)PGM_ENT;
-            ovf[lane] = ov ? 1u : 0u;
-#pragma unroll
-            for (int k = 0; k < PGM_KX; ++k) {
-                if ((uint32_t)k < cnt && base + k < (uint32_t)PGM_ENT) {
-                    el_a[base + k] = ov ? (uint32_t)lane : (rk8[k] | (uint32_t)lane);
-                    el_c[base + k] = ov ? INFINITY : cyv[k];
-                }
-            }
-        }
-
-        if (sweeper) {
-            // =========================================== main wavefront ===========================================
-            float W_left = PGM_NEG_INF, X_left = PGM_NEG_INF, W_diag = PGM_NEG_INF;
-            float W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
-            float4 pfq[PFQ];
-            constexpr int PFR = BL * HR / 64;
-            float2 pfr[PFR];
-            float4 pfs[BL / 4];
-            auto load_ring_block = [&](uint32_t c0) {
-#pragma unroll
-                for (int u = 0; u < PFQ; ++u) {
-                    const int idx = lane + 64 * u;
-                    const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx < BL * NQ && col <= ncol) v = pgm_gload4(ni2q + (size_t)NQ * col + (idx % NQ));
-                    pfq[u] = v;
-                }
-            };
-            auto store_ring_block = [&](uint32_t c0) {
-#pragma unroll
-                for (int u = 0; u < PFQ; ++u) {
-                    const int idx = lane + 64 * u;
-                    const uint32_t col = c0 + (uint32_t)(idx / NQ);
-                    if (idx < BL * NQ) ring[(col % R) * NQ + (idx % NQ)] = pfq[u];
-                }
-            };
-            auto load_rep_block = [&](uint32_t s0) {
-#pragma unroll
-                for (int u = 0; u < PFR; ++u) {
-                    const int e = lane * PFR + u;
-                    const uint32_t st = s0 + (uint32_t)(e / HR) + (uint32_t)RC;
-                    const int l = e % HR;
-                    float2 v = make_float2(PGM_NEG_INF, PGM_NEG_INF);
-                    if (has_prev && st < tsteps) v = pgm_gload_cell_wy(cells_prev + (size_t)st * 64u + (uint32_t)(RC + l));
-                    pfr[u] = v;
-                }
-            };
-            auto store_rep_block = [&]() {
-#pragma unroll
-                for (int u = 0; u < PFR; ++u) rep[lane * PFR + u] = pfr[u];
-            };
-            auto load_s_block = [&](uint32_t s0) {
-                const uint32_t tb = s0 / BL;
-#pragma unroll
-                for (int q = 0; q < BL / 4; ++q) {
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (comp && tb < nblk) v = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
-                    pfs[q] = v;
-                }
-            };
-            auto store_s_block = [&](uint32_t s0) {   // scores of the block starting at step s0 -> buffer (s0 / BL) & 1
-                float *dst = sblk + ((s0 / BL) & 1u) * (BL * 64);
-#pragma unroll
-                for (int q = 0; q < BL / 4; ++q) {
-                    dst[(4 * q) * 64 + lane] = pfs[q].x;
-                    dst[(4 * q + 1) * 64 + lane] = pfs[q].y;
-                    dst[(4 * q + 2) * 64 + lane] = pfs[q].z;
-                    dst[(4 * q + 3) * 64 + lane] = pfs[q].w;
-                }
-            };
-            int seen = has_prev ? 0 : 0x7fffffff, pend = 0;
-            unsigned long long wait_ticks = 0;   // timeline only: time spent waiting for band b-1
-            auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
-                if (seen != 0x7fffffff && !aborted) {
-                    const int need = (int)min(steps_needed, tsteps);
-                    uint32_t spins = 0;
-                    const unsigned long long w0 = (trace && seen < need) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                    while (seen < need) {
-                        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        if (seen >= need) break;
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > PGM_SPIN_LIMIT || __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            aborted = true;
-                            break;
-                        }
-                    }
-                    if (w0) wait_ticks += __builtin_amdgcn_s_memrealtime() - w0;
-                }
-            };
-            // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
-            // wait_prev only spins when that value is not far enough, i.e. when this band really has to wait for band b-1
-            auto poll_issue = [&]() { if (seen != 0x7fffffff) pend = __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)&J.prog[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-            auto poll_collect = [&]() { if (seen != 0x7fffffff) seen = max(seen, __builtin_amdgcn_readfirstlane(pend)); };
-            // prologue: column summaries and scores of blocks 0 and 1 straight in, block 2 in flight; replay tile of
-            // block 0 in, block 1 in flight
-            load_ring_block(0); store_ring_block(0);
-            load_s_block(0); store_s_block(0);
-            load_ring_block(BL); store_ring_block(BL);
-            load_s_block(BL); store_s_block(BL);
-            wait_prev(BL + RC + BL);
-            load_rep_block(0); store_rep_block();
-            load_ring_block(2 * BL);
-            load_s_block(2 * BL);
-            load_rep_block(BL);
-            poll_issue();
-            if (need_help) {
-                __syncthreads();   // history / counters initialised, first two blocks staged, entry list built
-                geny_m = geny || ovf[lane] != 0;
-                no_ent = __builtin_amdgcn_readfirstlane(el_cnt) == 0;   // helpers 2/3 idle: their result slots stay -inf
-            }
-
-            unsigned long long mcyc_wait = 0;
-            float2 aux_n = *(const float2 *)(ring + xr * NQ), rep_n = make_float2(PGM_NEG_INF, PGM_NEG_INF);   // operands of step 0
-            float S_n = sblk[lane];
-            const unsigned long long mc_start = CYCLES ? __builtin_readcyclecounter() : 0ull;
-            uint32_t ticks = 0;
-            for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
-                // LDS operands of a step are read one step ahead (aux2 / S of the next column are already staged; the replay
-                // tile only inside its block), so no LDS round trip sits between two steps of the chain.
-                rep_n = rep[lane & (HR - 1)];
-#pragma unroll
-                for (int i = 0; i < BL; ++i) {
-                    const uint32_t t = t0 + i;
-                    const int xs = (int)t - lane;
-                    const bool incol = xs >= 0 && xs < (int)ncol;
-                    const bool active = rowvalid && incol;
-                    const uint32_t x = (uint32_t)xs;
-                    const float2 aux = aux_n;
-                    const float S = S_n;
-                    const float2 rv = rep_n;
-                    xr = (xr + 1 == R) ? 0 : xr + 1;
-                    aux_n = *(const float2 *)(ring + xr * NQ);
-                    S_n = sblk[(((t + 1) / BL) & 1u) * (BL * 64) + ((t + 1) % BL) * 64 + lane];
-                    rep_n = rep[min(i + 1, BL - 1) * HR + (lane & (HR - 1))];
-                    const float ccx = aux.x;
-                    const uint32_t fx = __float_as_uint(aux.y);
-                    const bool genx = active && (fx & 8u) != 0;
-                    const bool xkill = active && (fx & 16u) != 0;
-                    const float gopen_y = (xs == 0) ? sg : gi;
-                    const float W_up = pgm_dpp_wave_shr1(W_o, PGM_NEG_INF);
-                    const float Y_up = pgm_dpp_wave_shr1(Y_o, PGM_NEG_INF);
-                    float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_diag, S), ccy), ccx);
-                    float Xv = __fsub_rn(fmaxf(__fadd_rn(X_left, ge), __fadd_rn(W_left, gopen_x)), ccx);
-                    float Yv = __fsub_rn(fmaxf(__fadd_rn(Y_up, ge), __fadd_rn(W_up, gopen_y)), ccy);
-                    const bool overflow = active && dymax + ((fx >> 8) & 255u) > (uint32_t)(H - 1);
-                    if (need_help) {
-                        // tick t: the helpers have finished the partial maxima of step t (and start on step t + 1, which
-                        // needs the history up to step t - 1, complete since the previous iteration)
-                        const unsigned long long mc0 = CYCLES ? __builtin_readcyclecounter() : 0ull;
-                        tick();
-                        ++ticks;
-                        if (CYCLES) mcyc_wait += __builtin_readcyclecounter() - mc0;
-                        const float *r1 = res1 + (t & 1u) * (2 * 64) + lane;
-                        float *ra = resA + (t & 1u) * (2 * 64) + lane;
-                        const float m1 = r1[0], x1 = r1[64];
-                        float m2 = PGM_NEG_INF, y2 = PGM_NEG_INF;
-                        if (!no_ent) {
-                            m2 = ra[0]; y2 = ra[64];
-                            ra[0] = PGM_NEG_INF; ra[64] = PGM_NEG_INF;     // slot is reused by step t + 2
-                        }
-                        if (!overflow) {
-                            Mv = fmaxf(Mv, fmaxf(m1, m2));
-                            Xv = fmaxf(Xv, x1);
-                            Yv = fmaxf(Yv, y2);
-                        }
-                    }
-                    const bool gen = active && (geny_m || genx || overflow);
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(gen) != 0, 0)) {
-                        if (gen) {
-                            const uint32_t xbx = (uint32_t)pgm_gld(J.xp2 + x), xex = (uint32_t)pgm_gld(J.xp2 + x + 1);
-                            for (uint32_t e = xby; e < xey; ++e) {
-                                const uint32_t yp = pgm_gld(J.xc1 + e);
-                                const float cy = pgm_gld(J.xv1 + e);
-                                const float2 c = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x));
-                                Yv = fmaxf(Yv, __fsub_rn(fmaxf(__fadd_rn(c.y, ge), __fadd_rn(c.x, gopen_y)), cy));
-                                if (x > 0) {
-                                    const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, x - 1));
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), cy), ccx));
-                                }
-                                for (uint32_t f = xbx; f < xex; ++f) {
-                                    const uint32_t xp = pgm_gld(J.xc2 + f);
-                                    const float cx = pgm_gld(J.xv2 + f);
-                                    const float2 c3 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, yp, xp));
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c3.x, S), cy), cx));
-                                }
-                            }
-                            for (uint32_t f = xbx; f < xex; ++f) {
-                                const uint32_t xp = pgm_gld(J.xc2 + f);
-                                const float cx = pgm_gld(J.xv2 + f);
-                                const float4 *cp = J.cells + pgm_cell_index(J, y, xp);
-                                const float2 cm = pgm_load_cell_mx(cp), cw = pgm_load_cell_wy(cp);
-                                Xv = fmaxf(Xv, __fsub_rn(fmaxf(__fadd_rn(cm.y, ge), __fadd_rn(cw.x, gopen_x)), cx));
-                                if (y > 0) {
-                                    const float2 c2 = pgm_load_cell_wy(J.cells + pgm_cell_index(J, y - 1, xp));
-                                    Mv = fmaxf(Mv, __fsub_rn(__fsub_rn(__fadd_rn(c2.x, S), ccy), cx));
-                                }
-                            }
-                        }
-                    }
-                    if (ykill) Xv = PGM_NEG_INF;
-                    if (xkill) Yv = PGM_NEG_INF;
-                    float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
-                    if (rowvalid && y == 0 && xs == 0) Wv = s_init;
-                    if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
-                    if (!comp) {
-                        Wv = incol ? rv.x : PGM_NEG_INF;
-                        Yv = incol ? rv.y : PGM_NEG_INF;
-                    }
-                    pgm_store_cell_masked(cells_rsrc, t, lane, active, Mv, Xv, Wv, Yv);
-                    if (active) {
-                        W_left = Wv;
-                        X_left = Xv;
-                    }
-                    if (need_help) {
-                        const int ho = (int)((t & (H - 1)) << 6) + lane;
-                        hW[ho] = Wv;
-                        hY[ho] = Yv;
-                        hX[ho] = Xv;
-                    }
-                    W_diag = W_up;
-                    W_o = Wv;
-                    Y_o = Yv;
-                }
-                if (has_next) {
-                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
-                    if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                // Stage the block after the next one.  This sits at the END of the iteration so that, on every path into
-                // it, exactly the BL cell stores of this block were issued after the prefetch loads consumed here: the
-                // compiler then waits for them with vmcnt(BL) instead of vmcnt(0), i.e. the wavefront never drains the
-                // stores it has just issued (~2 us of write-through latency per block otherwise).
-                const uint32_t t1 = t0 + BL;
-                if (t1 < tsteps) {
-                    store_ring_block(t1 + BL);     // one block before use (helpers run ahead of this wavefront)
-                    store_s_block(t1 + BL);
-                    store_rep_block();
-                    load_ring_block(t1 + 2 * BL);
-                    load_s_block(t1 + 2 * BL);
-                    poll_collect();
-                    wait_prev(t1 + BL + BL + RC);
-                    load_rep_block(t1 + BL);
-                    poll_issue();
-                }
-            }
-            if (CYCLES && lane == 0) { J.map1[8 * b] = (uint32_t)(mcyc_wait / tsteps); J.map1[8 * b + 1] = (uint32_t)((__builtin_readcyclecounter() - mc_start) / tsteps); }
-            if (need_help && aborted) {
-                // a hand-off timed out: tell the helpers (read after the band's last barrier) and serve the remaining ticks
-                if (lane == 0) __hip_atomic_store(&lds_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                for (const uint32_t tend = (tsteps + BL - 1) / BL * BL; ticks < tend; ++ticks) tick();
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)role < item.count) {
+            unsigned long long wait_ticks = 0;
+            const bool stall = item.job == stall_job && b == stall_band;
+            uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
+            if (J.has_extras) pgm_sweep_band<true>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? &wait_ticks : nullptr);
+            else pgm_sweep_band<false>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? &wait_ticks : nullptr);
             if (trace && threadIdx.x == 0) trace[6 * it] |= wait_ticks << 16;   // (wavefront 0 of the worker; worker id in the low 16 bits)
-        } else if (need_help) {
-            // =========================================== helper wavefronts ==========================================
-            __syncthreads();   // matches the main wavefront's barrier after initialisation
-            const int h = role - 1;
-            const uint32_t tend = (tsteps + BL - 1) / BL * BL;   // the main wavefront always finishes its last block
-            unsigned long long hcyc_wait = 0, hcyc_all = 0, hc_prev = CYCLES ? __builtin_readcyclecounter() : 0ull;
-            if (h == 0) {
-                // ---- helper 1: column extras, one row per lane like the main wavefront -----------------------------
-                // The column summary and the score of step t + 1 are read before the barrier of step t (they do not
-                // depend on the history), so after the barrier only the history reads remain.
-                float4 n_aux = ring[xr * NQ], n_q1 = ring[xr * NQ + 1], n_q2 = ring[xr * NQ + 2], n_q3 = ring[xr * NQ + 3];
-                float n_S = sblk[lane];
-                for (uint32_t t = 0; t < tend; ++t) {
-                    const float4 aux = n_aux, q1 = n_q1, q2 = n_q2, q3 = n_q3;
-                    const float S = n_S;
-                    const uint32_t fx = __float_as_uint(aux.y);
-                    const int nxw = pgm_wave_max8(fx & 7u);
-                    const uint32_t t8 = t << 8;
-                    float Mn = PGM_NEG_INF, Xn = PGM_NEG_INF;
-                    uint32_t cj8[PGM_KX];
-                    float cxv[PGM_KX];
-                    cj8[0] = __float_as_uint(aux.z); cj8[1] = __float_as_uint(aux.w);
-                    cj8[2] = __float_as_uint(q1.x); cj8[3] = __float_as_uint(q1.y); cj8[4] = __float_as_uint(q1.z); cj8[5] = __float_as_uint(q1.w);
-                    cj8[6] = __float_as_uint(q2.x);
-                    cxv[0] = q2.y; cxv[1] = q2.z; cxv[2] = q2.w; cxv[3] = q3.x; cxv[4] = q3.y; cxv[5] = q3.z; cxv[6] = q3.w;
-                    if (nxw > 0) part_cols(t8, nxw, cj8, cxv, S, Mn, Xn);
-                    float *rs = res1 + (t & 1u) * (2 * 64) + lane;
-                    rs[0] = Mn; rs[64] = Xn;
-                    xr = (xr + 1 == R) ? 0 : xr + 1;
-                    n_aux = ring[xr * NQ]; n_q1 = ring[xr * NQ + 1]; n_q2 = ring[xr * NQ + 2]; n_q3 = ring[xr * NQ + 3];
-                    n_S = sblk[(((t + 1) / BL) & 1u) * (BL * 64) + ((t + 1) % BL) * 64 + lane];
-                    const unsigned long long hcb = CYCLES ? __builtin_readcyclecounter() : 0ull;
-                    tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (CYCLES) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
-                }
-            } else {
-                // ---- helpers 2 and 3: one ROW EXTRA (entry) per lane -----------------------------------------------
-                // A lane owns entry (row lane l, distance d, cost cy) for the whole band and evaluates, for the column
-                // x = t - l that row is at: helper 2 the row terms (Y, M with the chain column) and the pairs with
-                // column extras 0..2; helper 3 the pairs with column extras 3..6.  Rows have ~1 extra on average but
-                // up to 7, so a lane per entry does a few times less work than a lane per row with a loop to the
-                // wavefront's maximum count.  Results are merged per owner row with LDS float-max atomics (max is
-                // exact and order independent).  Up to PGM_ENT = 128 entries (two per lane).
-                const int nent = min(el_cnt, (int)PGM_ENT);
-                const bool two = nent > 64;
-                uint32_t e_l[2], e_rk8[2], e_lk4[2];
-                int e_xr[2];
-                float e_cy[2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int w = lane + 64 * p;
-                    const bool valid = w < nent;
-                    const uint32_t a = valid ? el_a[w] : (uint32_t)lane;
-                    e_cy[p] = valid ? el_c[w] : INFINITY;
-                    e_l[p] = a & 255u;
-                    e_rk8[p] = a & ~255u;
-                    e_lk4[p] = e_l[p] * 4u - (e_rk8[p] >> 6);
-                    e_xr[p] = (R - (int)e_l[p]) % R;
-                }
-                // column data and score of the owner's next column are read before the barrier (see helper 1)
-                float S[2], ccx[2], gopen_y[2];
-                uint32_t dj[2][4];
-                float cxs[2][4];
-                bool any = false;
-                auto fetch_cols = [&](uint32_t t) {
-                    const float *sb = sblk + ((t / BL) & 1u) * (BL * 64) + (t % BL) * 64;
-                    any = false;
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        if (p == 0 || two) {
-                            const float4 *rc = ring + e_xr[p] * NQ;
-                            e_xr[p] = (e_xr[p] + 1 == R) ? 0 : e_xr[p] + 1;
-                            S[p] = sb[e_l[p]];
-                            if (h == 1) {
-                                const float4 aux = rc[0], q2 = rc[2];
-                                const float q1x = rc[1].x;
-                                ccx[p] = aux.x;
-                                gopen_y[p] = (t == e_l[p]) ? sg : gi;
-                                dj[p][0] = __float_as_uint(aux.z); dj[p][1] = __float_as_uint(aux.w); dj[p][2] = __float_as_uint(q1x); dj[p][3] = 0u;
-                                cxs[p][0] = q2.y; cxs[p][1] = q2.z; cxs[p][2] = q2.w; cxs[p][3] = INFINITY;
-                                any = true;
-                            } else {
-                                const float4 q1 = rc[1], q3 = rc[3];
-                                const float q2x = rc[2].x;
-                                dj[p][0] = __float_as_uint(q1.y); dj[p][1] = __float_as_uint(q1.z); dj[p][2] = __float_as_uint(q1.w); dj[p][3] = __float_as_uint(q2x);
-                                cxs[p][0] = q3.x; cxs[p][1] = q3.y; cxs[p][2] = q3.z; cxs[p][3] = q3.w;
-                                any = any || (q3.x < INFINITY && e_cy[p] < INFINITY);   // column extra 3 exists (they are filled in order)
-                            }
-                        }
-                    }
-                };
-                // a band without row extras (most bands of a light merged graph): nothing to evaluate, only keep the ticks
-                // (helper 3 evaluates the pairs with column extras 3..6: idle too if no column of the job has more than three)
-                if (nent == 0 || (h == 2 && J.max_cx <= 3u)) {
-                    for (uint32_t t = 0; t < tend; ++t) tick();
-                } else {
-                fetch_cols(0);
-                for (uint32_t t = 0; t < tend; ++t) {
-                    const uint32_t t8 = t << 8;
-                    const bool work = __builtin_amdgcn_ballot_w64(any) != 0;
-                    if (work) {
-                        float *ra = resA + (t & 1u) * (2 * 64);
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            if (p == 0 || two) {
-                                const uint32_t tk8 = t8 - e_rk8[p];
-                                float W2[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (h == 2 || j < 3) W2[j] = *(const float *)(hWb + (((tk8 - dj[p][j]) & MW) | e_lk4[p]));
-                                float Mt = PGM_NEG_INF;
-                                if (h == 1) {
-                                    const float Wk = *(const float *)(hWb + ((tk8 & MW) | e_lk4[p]));
-                                    const float Yk = *(const float *)(hYb + ((tk8 & MH) | e_lk4[p]));
-                                    const float W1 = *(const float *)(hWb + (((tk8 - 256u) & MW) | e_lk4[p]));
-                                    const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yk, ge), __fadd_rn(Wk, gopen_y[p])), e_cy[p]);
-                                    Mt = __fsub_rn(__fsub_rn(__fadd_rn(W1, S[p]), e_cy[p]), ccx[p]);
-                                    __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(ra + 64 + e_l[p]), Yt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-                                }
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (h == 2 || j < 3) Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(W2[j], S[p]), e_cy[p]), cxs[p][j]));
-                                __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(ra + e_l[p]), Mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-                            }
-                        }
-                    }
-                    fetch_cols(t + 1);
-                    const unsigned long long hcb = CYCLES ? __builtin_readcyclecounter() : 0ull;
-                    tick();   // partial maxima of step t complete; the main wavefront has finished step t - 1
-                    if (CYCLES) { const unsigned long long hc2 = __builtin_readcyclecounter(); hcyc_wait += hc2 - hcb; hcyc_all += hc2 - hc_prev; hc_prev = hc2; }
-                }
-                }
-            }
-            if (CYCLES && lane == 0) { J.map1[8 * b + 2 + 2 * h] = (uint32_t)(hcyc_wait / tend); J.map1[8 * b + 3 + 2 * h] = (uint32_t)(hcyc_all / tend); }
         }
-        if (need_help) {
-            __syncthreads();   // band finished: nobody reads the history any more
-            if (lds_abort != 0) aborted = true;
-        }
-        }   // band body
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         if (last_band) {
             // The last band of a job is the last one to finish, and every cell of the job is written through to memory
-            // by now: this worker walks the traceback (all four wavefronts; helpers of a chain-only job join here).
+            // by now: this worker walks the traceback (all four wavefronts, whatever they did in this item).
             __syncthreads();
             if (threadIdx.x == 0) {
-                const bool ok = !aborted && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+                const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
                 if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; *J.hresult = *J.result; }
                 tb_go = ok ? 1 : 0;
             }
             __syncthreads();
-            if (tb_go != 0 && !CYCLES) {
+            if (tb_go != 0 && !NOTRACEBACK) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
                 pgm_traceback_job(J, L.t, (int)threadIdx.x, 256, trace ? trace + 6 * it + 4 : nullptr);
             }
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Dense emission matrix (test hook only): S[y + n1*x] for all nodes, same arithmetic as the fill.
-__global__ void __launch_bounds__(256) pgm_emission_kernel(const PgmJob *__restrict__ jobs, uint32_t job, float *__restrict__ S) {
-    const PgmJob &J = jobs[job];
-    const size_t N = (size_t)J.n1 * J.n2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t y = (uint32_t)(i % J.n1), x = (uint32_t)(i / J.n1);
-        const float *g = J.g1f + (size_t)J.dp * y;
-        const float *tt = J.t2 + (size_t)J.dp * x;
-        float acc = 0.0f;
-        for (uint32_t k = 0; k < J.dim; ++k) acc = __fadd_rn(acc, __fmul_rn(g[k], tt[k]));
-        S[i] = pgm_emission_finish(acc, J.a1[y], J.b2[x], J.sc.match_init);
     }
 }
 

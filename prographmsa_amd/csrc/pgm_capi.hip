@@ -144,8 +144,9 @@ int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count
 namespace {
 struct SideOff {
     size_t sites, ni, xp, xc, xv, pp, pc, pv, pu;
-    uint32_t nodes_with_extras;
-    uint32_t max_on_chip;   // largest number of extras of one node that are served from the on-chip history (0..7)
+    uint32_t nodes_with_extras;   // nodes with a predecessor other than the chain neighbour
+    uint32_t far_nodes;           // nodes with entries served from the LDS history
+    uint32_t maxd;                // largest on-chip predecessor distance of the graph (>= 1)
 };
 
 static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
@@ -154,11 +155,28 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     std::vector<float> xv, pv;
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
-    std::vector<PgmNodeInfo> ni(n);
+    std::vector<PgmNode2> ni(n);
+    o.nodes_with_extras = 0; o.far_nodes = 0; o.maxd = 1;
     for (uint32_t v = 0; v < n; ++v) {
-        PgmNodeInfo &I = ni[v];
+        PgmNode2 &I = ni[v];
         memset(&I, 0, sizeof I);
-        I.cc = INFINITY;
+        I.cc = I.c2 = I.c3 = INFINITY;
+        for (int k = 0; k < PGM_KF; ++k) I.fc[k] = INFINITY;
+        uint32_t nfar = 0, dmax = 1;
+        bool generic = false;
+        // near slots: the first finite-cost edge from node-1 / node-2 / node-3; everything else is a far entry (an edge of
+        // infinite cost contributes -inf to every maximum: it only stays in the CSR lists)
+        auto place = [&](uint32_t from, float val) {
+            const uint32_t d = v - from;
+            if (d == 1 && I.cc == INFINITY && val != INFINITY) { I.cc = val; return; }
+            xc.push_back(from); xv.push_back(val);
+            if (val == INFINITY) return;
+            if (d == 2 && I.c2 == INFINITY) { I.c2 = val; dmax = std::max(dmax, d); return; }
+            if (d == 3 && I.c3 == INFINITY) { I.c3 = val; dmax = std::max(dmax, d); return; }
+            if (nfar >= (uint32_t)PGM_KF || d > (uint32_t)PGM_DCAP) { generic = true; return; }
+            I.fd[nfar] = d; I.fc[nfar] = val; ++nfar;
+            dmax = std::max(dmax, d);
+        };
         const int32_t eb = g->e_rowptr[v], ee = g->e_rowptr[v + 1];
         if (eb > ee || eb < 0) return PGM_ERR_INVALID;
         for (int32_t e = eb; e < ee; ++e) {
@@ -167,49 +185,38 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
             const float c = g->e_val[e];
             const float val = (c == 0) ? INFINITY : c + 10000.0f;  // PredIterator::value, Graph.h:223-231
             pc.push_back(from); pv.push_back(val); pu.push_back(0u);
-            if (from + 1 == v && I.cc == INFINITY && val != INFINITY) I.cc = val;
-            else { xc.push_back(from); xv.push_back(val); }
+            place(from, val);
         }
         if (g->r_rowptr) {
+            if (g->r_rowptr[v] > g->r_rowptr[v + 1] || g->r_rowptr[v] < 0) return PGM_ERR_INVALID;
             for (int32_t e = g->r_rowptr[v]; e < g->r_rowptr[v + 1]; ++e) {
                 const uint32_t from = g->r_col[e];
                 if (from >= v) return PGM_ERR_INVALID;
                 const uint32_t units = g->r_units[e];
                 const float val = (units == 0) ? INFINITY : sc.repeat_init + sc.repeat_ext * (float)(units - 1);  // Graph.h:232-238
                 pc.push_back(from); pv.push_back(val); pu.push_back(0x80000000u | units);
-                xc.push_back(from); xv.push_back(val);
+                place(from, val);
             }
         }
         xp[v + 1] = (int32_t)xc.size();
         pp[v + 1] = (int32_t)pc.size();
-        // summary of the extras for the on-chip (LDS history) path of the fill kernel
-        const uint32_t nx = (uint32_t)(xp[v + 1] - xp[v]);
-        bool generic = nx > PGM_KX;
-        for (uint32_t k = 0; k < nx; ++k)
-            if (v - xc[xp[v] + k] > (uint32_t)(PGM_HIST - 1)) generic = true;
-        for (int k = 0; k < PGM_KX; ++k) { I.d[k] = 0; I.c[k] = INFINITY; }
-        if (!generic) {
-            I.flags = nx;
-            uint32_t dmax = 0;
-            for (uint32_t k = 0; k < nx; ++k) {
-                I.d[k] = (v - xc[xp[v] + k]) << 8;
-                I.c[k] = xv[xp[v] + k];
-                dmax = std::max(dmax, v - xc[xp[v] + k]);
-            }
-            I.flags |= dmax << 8;
+        if (generic) {   // every non-chain predecessor of this node goes through the CSR lists and the cell storage
+            I.c2 = I.c3 = INFINITY;
+            for (int k = 0; k < PGM_KF; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
+            I.flags = 8u | (1u << 8);
         } else {
-            I.flags = 8u;
+            I.flags = nfar | (dmax << 8);
+            o.maxd = std::max(o.maxd, dmax);
+            o.far_nodes += nfar != 0;
         }
         if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 16u;  // interior node without predecessors
+        o.nodes_with_extras += (xp[v + 1] > xp[v]);
     }
-    o.nodes_with_extras = 0;
-    o.max_on_chip = 0;
-    for (uint32_t v = 0; v < n; ++v) { o.nodes_with_extras += (xp[v + 1] > xp[v]); o.max_on_chip = std::max(o.max_on_chip, ni[v].flags & 7u); }
     // at least one element each so that pointers are valid
     if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
     if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
     o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);
-    o.ni = A.put(ni.data(), sizeof(PgmNodeInfo) * ni.size());
+    o.ni = A.put(ni.data(), sizeof(PgmNode2) * ni.size());
     o.xp = A.put(xp.data(), 4 * xp.size());
     o.xc = A.put(xc.data(), 4 * xc.size());
     o.xv = A.put(xv.data(), 4 * xv.size());
@@ -258,16 +265,21 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
     const dim3 eg((b->maxnblk + PGM_EM_TB - 1) / PGM_EM_TB, (b->maxnb + 3) / 4, b->njobs);
-    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20>), eg, dim3(192), 0, s, b->d_jobs);
-    else hipLaunchKernelGGL((pgm_emission_skew_kernel<64>), eg, dim3(192), 0, s, b->d_jobs);
+    if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20>), eg, dim3(4 * PGM_ROWS), 0, s, b->d_jobs);
+    else hipLaunchKernelGGL((pgm_emission_skew_kernel<64>), eg, dim3(4 * PGM_ROWS), 0, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
     // One kernel does the DP fill of every band and, right after a job's last band, that job's traceback.
-    const char *dbg = getenv("PGM_FILL_DBG");   // 8: cycle-counter build of the fill kernel (tools/probe_cyc.py), no traceback
+    const char *dbg = getenv("PGM_FILL_DBG");   // 8: the fill alone, no traceback (tools)
     const int dbgv = dbg ? atoi(dbg) : 0;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace);
+    // test knobs for the hand-off time-out path (tests/test_gpu_align.py): a shorter spin limit, and one band of one job
+    // that never publishes its progress ("job:band"), so that the band below it times out and the batch aborts
+    uint32_t spin_limit = PGM_SPIN_LIMIT, stall_job = 0xFFFFFFFFu, stall_band = 0;
+    if (const char *v = getenv("PGM_TEST_SPIN_LIMIT")) spin_limit = (uint32_t)std::max(1, atoi(v));
+    if (const char *v = getenv("PGM_TEST_STALL")) { unsigned a = 0, c = 0; if (sscanf(v, "%u:%u", &a, &c) == 2) { stall_job = a; stall_band = c; } }
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
@@ -297,7 +309,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         size_t E = (size_t)std::max(0, g->e_rowptr ? g->e_rowptr[n] : 0);
         if (g->r_rowptr) E += (size_t)std::max(0, g->r_rowptr[n]);
         E = std::max<size_t>(E, 1);
-        return n * g->dim * 8 + n * sizeof(PgmNodeInfo) + 2 * (n + 1) * 4 + E * 20 + 16 * 16;
+        return n * g->dim * 8 + n * sizeof(PgmNode2) + 2 * (n + 1) * 4 + E * 20 + 16 * 16;
     };
     std::vector<size_t> in_base(njobs + 1, 0);
     for (uint32_t i = 0; i < njobs; ++i) {
@@ -361,7 +373,16 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 Off &o = off[i];
                 if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); continue; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
-                J.max_cx = o.s2.max_on_chip;
+                J.has_far = (o.s1.far_nodes + o.s2.far_nodes) > 0 ? 1u : 0u;
+                // LDS of one sweeping wavefront: W / Y history of hD steps x (64 lanes + 16 virtual lanes), X history of hDX
+                // steps x 64 lanes, 128 column summaries.  A pair (y - dy, x - dx) is read dy + dx steps back and the virtual
+                // lanes are written a block ahead: hD >= maxd1 + maxd2 + 8, hDX >= maxd2 + 1 (powers of two).
+                uint32_t hD = 16, hDX = 4;
+                while (hD < o.s1.maxd + o.s2.maxd + (uint32_t)PGM_BLOCK) hD *= 2;
+                while (hDX < o.s2.maxd + 1) hDX *= 2;
+                J.hD = hD; J.hDX = hDX;
+                J.slot_bytes = 2u * hD * (64u + PGM_VL) * 4u + hDX * 64u * 4u + PGM_NRING * 48u;
+                J.nslots = std::max(1u, std::min(4u, (uint32_t)PGM_POOL / J.slot_bytes));
                 o.M = A.put(model[i]->M, sizeof(double) * J.dim * J.dim);
                 o.pi = A.put(model[i]->pi, sizeof(double) * J.dim);
                 if (A.overflow) bad.store((int)i);
@@ -408,7 +429,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         uint8_t *in = b->d_in, *w = b->d_work, *ob = b->d_out;
         J.sites1 = (const double *)(in + o.s1.sites); J.sites2 = (const double *)(in + o.s2.sites);
         J.M = (const double *)(in + o.M); J.pi = (const double *)(in + o.pi);
-        J.ni1 = (const PgmNodeInfo *)(in + o.s1.ni); J.ni2 = (const PgmNodeInfo *)(in + o.s2.ni);
+        J.ni1 = (const PgmNode2 *)(in + o.s1.ni); J.ni2 = (const PgmNode2 *)(in + o.s2.ni);
         J.xp1 = (const int32_t *)(in + o.s1.xp); J.xp2 = (const int32_t *)(in + o.s2.xp);
         J.xc1 = (const uint32_t *)(in + o.s1.xc); J.xc2 = (const uint32_t *)(in + o.s2.xc);
         J.xv1 = (const float *)(in + o.s1.xv); J.xv2 = (const float *)(in + o.s2.xv);
@@ -439,27 +460,25 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // free it takes, among the items that are READY by then, the one with the longest remaining path (the time until its
     // job is complete: the lags still ahead, one full sweep, the traceback).  Within a job the items keep ascending
     // order, as the kernel requires; taking only ready items keeps workers from idling in front of a predecessor band.
-    // Step times: ~0.38 us for a chain-only band (main wavefront alone), ~0.7 us in lock-step with the helpers.
+    // Step times (us, one wavefront per band): ~0.2 for a chain-only band, ~0.35 with the near-predecessor window.
     std::vector<PgmItem> items;
     uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
-    // persistent workers: 2 workgroups of 4 wavefronts per CU.  A third would fit, but co-resident workers slow each other
-    // down and the batch's makespan is its longest job's critical path: measured on the 256 x 1000 batch 7.3 / 6.6 / 7.0 ms
-    // at 1.5 / 2 / 2.5 per CU (tools/probe_trace.py)
-    if (const char *env_c = getenv("PGM_FILL_WORKERS"))   // experiments only (at most 3 per CU fit)
-        capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount * 3u, (uint32_t)std::max(1, atoi(env_c)));
+    // persistent workers: 2 workgroups of 4 wavefronts per CU (each owns half of the CU's LDS for its sweeps' histories)
+    if (const char *env_c = getenv("PGM_FILL_WORKERS"))   // experiments only
+        capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount * 2u, (uint32_t)std::max(1, atoi(env_c)));
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
         std::vector<std::vector<Item>> per_job(njobs);
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };   // experiments only
-        const double tau_x = envd("PGM_SIM_TAU_X", 0.7), tau_c = envd("PGM_SIM_TAU_C", 0.38), eager = envd("PGM_SIM_EAGER", 0.7);
+        const double tau_x = envd("PGM_SIM_TAU_X", 0.35), tau_c = envd("PGM_SIM_TAU_C", 0.2), eager = envd("PGM_SIM_EAGER", 0.7);
         size_t total = 0;
         double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
             const double tau = J.has_extras ? tau_x : tau_c;     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
-            const uint32_t group = J.has_extras ? 1u : 4u;       // chain-only jobs: four bands per item, one per wavefront
+            const uint32_t group = J.nslots;                     // bands per item, one per wavefront of the worker
             for (uint32_t band = 0; band < J.nb; band += group) {
                 const uint32_t cnt = std::min(group, J.nb - band);
                 const bool last = band + cnt == J.nb;
@@ -649,13 +668,16 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
             }
     }
     if (S) {
-        float *dS = nullptr;
-        HIPCHK(hipMalloc((void **)&dS, N * sizeof(float)));
-        hipLaunchKernelGGL(pgm_emission_kernel, dim3(512), dim3(256), 0, ctx->stream, b->d_jobs, job, dS);
-        hipError_t e = hipMemcpyAsync(S, dS, N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(dS);
-        if (e != hipSuccess) return fail(PGM_ERR_DEVICE, hipGetErrorString(e));
+        // the emission scores exactly as the fill kernel consumes them (PgmJob::S, written by pgm_emission_skew_kernel), de-skewed
+        const size_t ns = (size_t)J.nb * J.nblk * 64u * PGM_BLOCK;
+        std::vector<float> sk(ns);
+        HIPCHK(hipMemcpy(sk.data(), J.S, ns * sizeof(float), hipMemcpyDeviceToHost));
+        std::fill(S, S + N, 0.0f);
+        for (uint32_t y = 0; y + 1 < J.n1; ++y)
+            for (uint32_t x = 0; x < J.ncol; ++x) {
+                const uint32_t bb = y / PGM_ROWS, l = PGM_HALO + (y - bb * PGM_ROWS), t = x + l;
+                S[(size_t)y + (size_t)J.n1 * x] = sk[(((size_t)bb * J.nblk + t / PGM_BLOCK) * 64u + l) * PGM_BLOCK + t % PGM_BLOCK];
+            }
     }
     return PGM_OK;
 }

@@ -5,41 +5,40 @@
 #include <stdint.h>
 #include "../../include/pgm_hip.h"
 
-#define PGM_HALO 16        /* lanes 0..15 of a band replay the last 16 rows of the previous band */
-#define PGM_ROWS 48        /* rows computed per band = 64 lanes - PGM_HALO */
+#define PGM_HALO 0         /* every lane of a band owns a row (the rows above the band are "virtual lanes" in the LDS history) */
+#define PGM_ROWS 64        /* rows per band = lanes of the sweeping wavefront */
+#define PGM_VL 16          /* virtual lanes: the last 16 rows of the previous band, kept in the LDS history of the band below */
 #define PGM_BLOCK 8        /* steps between two synchronisation points of a band */
-#define PGM_HIST 32        /* steps of W/X/Y history kept in LDS per wavefront */
-#define PGM_RING 80        /* columns of T = M^T g2 kept in LDS per wavefront */
+#define PGM_NRING 128      /* columns of graph 2 whose predecessor summary is kept in LDS per sweeping wavefront */
+#define PGM_KF 4           /* "far" predecessors per node served from the LDS history */
+#define PGM_DCAP 28        /* largest predecessor distance served on chip (farther: generic path through the cell storage) */
+#define PGM_POOL 81408     /* LDS bytes of a fill worker (two workers per CU: 2 x (81408 + 512) = 160 KiB) */
 
-// Per-node predecessor summary prepared by the host from the CSR (64 bytes = 4 float4).
-//   q0 = {cc, flags, d0, d1}   q1 = {d2, d3, d4, d5}   q2 = {d6, c0, c1, c2}   q3 = {c3, c4, c5, c6}
-//   cc     cost of the chain edge (node-1 -> node), +inf if absent
-//   flags  bits 0-2: number n of other ("extra") predecessors served from the on-chip history (n <= 7)
-//          bits 8-15: largest distance among them
-//          bit 3   : generic — more than 7 extras or a distance > 31: every extra of this node is read from the
-//                    cell storage through the CSR lists (xp/xc/xv); then n = 0 and all d = 0, c = +inf
+// Per-node predecessor summary prepared by the host from the CSR (48 bytes = 3 float4).
+//   q0 = {cc, c2, c3, flags}   q1 = {fd0..fd3}   q2 = {fc0..fc3}
+//   cc, c2, c3  cost of the edge from node-1 / node-2 / node-3 ("near" predecessors, served from registers of the
+//               sweeping wavefront), +inf if absent: an absent edge then contributes -inf to every max without masking
+//   flags  bits 0-2: number of "far" predecessors (any other edge; <= PGM_KF), served from the on-chip history
+//          bits 8-15: largest distance among all on-chip predecessors of the node (>= 1)
+//          bit 3   : generic — more than PGM_KF far edges or a distance > PGM_DCAP: every non-chain predecessor of this
+//                    node is read from the cell storage through the CSR lists (xp/xc/xv); then c2 = c3 = +inf, no far entries
 //          bit 4   : kill — interior node without any predecessor
-//   d_k    (node - predecessor) << 8 of extra k, 0 if absent;   c_k its cost, +inf if absent (an absent
-//          extra therefore contributes -inf to every max without any masking)
-#define PGM_KX 7
-#define PGM_ENT 128       // row-extra entries per band handled by the entry wavefronts of the helper fill kernel
-struct PgmNodeInfo {
-    float cc;
+//   fd_k   (node - predecessor) of far edge k, 0 if absent;   fc_k its cost, +inf if absent
+struct PgmNode2 {
+    float cc, c2, c3;
     uint32_t flags;
-    uint32_t d[PGM_KX];
-    float c[PGM_KX];
+    uint32_t fd[PGM_KF];
+    float fc[PGM_KF];
 };
-#define PGM_HISTW 32       /* steps of W history (pairs reach back dy+dx steps) */
 
 // One alignGraphs job, resident in HBM.  All pointers are device pointers.
 //
 // DP storage ("cells"): the reference keeps four n1 x n2 column-major float matrices M,X,Y,W
 // (GraphAlign.h:206-209).  Here a cell is one float4 {M,X,W,Y} and the matrix is stored in the order
-// the wavefronts produce it: rows are cut into bands of 48; a band is swept by one wavefront whose
-// lanes 16..63 own the band's rows (lanes 0..15 replay the last 16 rows of the previous band so that
-// near skip-edge predecessors are always inside the wavefront), with lane l one column behind lane
-// l-1, so "step" t of band b holds the cells (y = 48 b + l - 16, x = t - l) at
-// cells[((b * tsteps) + t) * 64 + l]  — every wave-level store is one contiguous 768 B run.
+// the wavefronts produce it: rows are cut into bands of 64; a band is swept by one wavefront whose
+// lane l owns row y = 64 b + l, with lane l one column behind lane l-1, so "step" t of band b holds
+// the cells (y = 64 b + l, x = t - l) at cells[((b * tsteps) + t) * 64 + l]  — every wave-level
+// store is one contiguous 1 KB run.
 // Rows 0..n1-2 and columns 0..n2-2 are stored (the END row/column are never written by the reference
 // either); row 0 / column 0 are the border initialisation of GraphAlign.h:212-234.
 // Predecessor record of one node for the traceback's tile staging: the first PGM_TB_PK entries of the node's list in
@@ -57,19 +56,22 @@ struct PgmTbNode {
 struct PgmJob {
     uint32_t n1, n2;       // node counts incl. START/END
     uint32_t dim, dp;      // alphabet size and padded size (multiple of 4)
-    uint32_t nb;           // number of row bands = ceil((n1-1)/48)
+    uint32_t nb;           // number of row bands = ceil((n1-1)/64)
     uint32_t ncol;         // stored columns = n2-1
     uint32_t tsteps;       // steps per band = ncol + 63
     uint32_t maxn;         // max(n1,n2)
     uint32_t has_extras;   // some node of either graph has a predecessor other than its chain neighbour
-    uint32_t max_cx;       // largest number of on-chip extras of a column (node of graph 2): helper 3 only has work if > 3
+    uint32_t has_far;      // some node has a predecessor served from the LDS history (the sweeps then record W, Y, X there)
+    uint32_t hD, hDX;      // depth (steps, power of two) of the W / Y history and of the X history of a sweeping wavefront
+    uint32_t slot_bytes;   // LDS bytes one sweeping wavefront needs for this job (history + column rings)
+    uint32_t nslots;       // bands of this job one worker sweeps at a time = min(4, PGM_POOL / slot_bytes)
     pgm_scores sc;
 
     // inputs as uploaded
     const double *sites1, *sites2;   // dim x n column-major
     const double *M, *pi;            // dim x dim column-major, dim
     // per-node edge data prepared by the host from the CSR (costs are float32 as in Graph.h:223-239)
-    const PgmNodeInfo *ni1, *ni2;    // chain cost + summary of the other predecessors
+    const PgmNode2 *ni1, *ni2;       // near costs + far entries of every node
     const int32_t *xp1, *xp2;        // CSR ptr of the remaining ("extra") predecessors, n+1 entries
     const uint32_t *xc1, *xc2;       // extra predecessor node
     const float *xv1, *xv2;          // extra predecessor cost (repeat edges already evaluated)
@@ -87,9 +89,9 @@ struct PgmJob {
     float *b2;             // [n2]      pi^T g2
 
     // emission scores produced by the emission kernel, in the order the fill kernel consumes them:
-    // S[((b * nblk + (t >> 4)) * 64 + lane) * 16 + (t & 15)] = S(y, x) of the cell lane `lane` of band b owns at step t
+    // S[((b * nblk + (t >> 3)) * 64 + lane) * 8 + (t & 7)] = S(y, x) of the cell lane `lane` of band b owns at step t
     float *S;
-    uint32_t nblk;         // ceil(tsteps / 16)
+    uint32_t nblk;         // ceil(tsteps / 8)
 
     // DP storage
     float4 *cells;         // [nb][tsteps][64]
@@ -107,9 +109,9 @@ struct PgmJob {
 };
 
 
-// One unit of fill work: `count` consecutive bands (48 rows each) of job `job`, starting at `band`: 1 for merged graphs
-// (one wavefront sweeps, three help), up to 4 for chain-only jobs (one band per wavefront).  The list is ordered so that
-// a job's bands come in ascending order (workers take the items in list order, see pgm_fill_kernel).
+// One unit of fill work: `count` consecutive bands (64 rows each) of job `job`, starting at `band`, one per wavefront of
+// the worker that takes the item (count <= PgmJob::nslots <= 4).  The list is ordered so that a job's bands come in
+// ascending order (workers take the items in list order, see pgm_fill_kernel).
 struct PgmItem {
     uint32_t job, band;
     uint32_t prio, count; // prio: wave priority 0..3 while the item (and a traceback that follows it) is processed

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import gen  # noqa: E402
 
 ONLY = None
-if "--only" in sys.argv:   # regenerate one section only (currently: nw_trees)
+if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size)
     i = sys.argv.index("--only")
     ONLY = sys.argv[i + 1]
     del sys.argv[i:i + 2]
@@ -53,10 +53,38 @@ def nw_trees():
     w("nw_trees.json", json.dumps(out, indent=0))
 
 
+def full_size():
+    """Full-size BASELINE configs 4 and 5, one progressive pass on a committed guide tree, md5 only (the inputs are
+    regenerated from the seeds by tests/gen.py): 128 x 1000 codons (--codon) and 1024 x 600 aa with the synthetic
+    K = 4000 context-profile library (gen.genlib(4000, 11), ~5 MB of text, not committed).  The reference needs ~10 s
+    and ~3-8 min for these two lines."""
+    md5 = json.load(open("md5.json"))
+    fa = gen.fasta(gen.gen_codon(128, 1000, 4))
+    w("c4.fa.tmp", fa)
+    w("c4.tree", run(["--codon", "-T", "-i", "0", "c4.fa.tmp"]))
+    md5["c4.fa"] = hashlib.md5(fa.encode()).hexdigest()
+    md5["c4.out.fa"] = hashlib.md5(run(["--codon", "--fasta", "-t", "c4.tree", "c4.fa.tmp"]).encode()).hexdigest()
+    os.remove("c4.fa.tmp")
+    fa = gen.fasta(gen.gen(1024, 600, 6))
+    w("c5.fa.tmp", fa)
+    lib = gen.genlib(4000, 11)
+    w("K4000syn.lib.tmp", lib)
+    w("c5.tree", run(["-T", "-i", "0", "c5.fa.tmp"]))
+    md5["c5.fa"] = hashlib.md5(fa.encode()).hexdigest()
+    md5["K4000syn.lib"] = hashlib.md5(lib.encode()).hexdigest()
+    md5["c5.cs.out.fa"] = hashlib.md5(run(["--fasta", "-t", "c5.tree", "--cs_profile", "K4000syn.lib.tmp", "c5.fa.tmp"]).encode()).hexdigest()
+    md5["c5.out.fa"] = hashlib.md5(run(["--fasta", "-t", "c5.tree", "c5.fa.tmp"]).encode()).hexdigest()
+    os.remove("c5.fa.tmp")
+    os.remove("K4000syn.lib.tmp")
+    w("md5.json", json.dumps(md5, indent=1))
+
+
 def main():
     os.chdir(HERE)
     if ONLY == "nw_trees":
         return nw_trees()
+    if ONLY == "full_size":
+        return full_size()
     md5 = {}
     # c1: 8 x 120 aa (BASELINE config 1), guide tree from the reference (-T), then --fasta --tree
     w("c1.fa", gen.fasta(gen.gen(8, 120, 1)))
@@ -154,6 +182,7 @@ def main():
         cnw[str(seed)] = dict(fasta=fa, ml=run(["--codon", "-a", "-m", "-T", "-i", "0", "pair.fa.tmp"]))
     w("nw_pairs_codon.json", json.dumps(cnw, indent=0))
     w("md5.json", json.dumps(md5, indent=1))
+    full_size()
     for f in ("c3.fa.tmp", "pair.fa.tmp", "pair.tree.tmp"):
         os.remove(f)
     print("golden fixtures regenerated in", HERE)

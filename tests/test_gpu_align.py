@@ -25,17 +25,25 @@ def _cmp_job(batch, idx, job, res):
     assert np.array_equal(res["map1"], ref["map1"]) and np.array_equal(res["map2"], ref["map2"])
 
 
-@pytest.mark.parametrize("kw", [
+FAMILIES = [
     dict(skip_frac=0.0, drop_chain_frac=0.0),                 # pure chains (leaf vs leaf)
-    dict(skip_frac=0.2),                                      # merged-graph like skip edges
+    dict(skip_frac=0.2),                                      # merged-graph like skip edges: near window + LDS history
     dict(skip_frac=0.3, repeat_frac=0.05),                    # + tandem-repeat edges
-    dict(skip_frac=0.95, skip_max=9, drop_chain_frac=0.0),    # dense extras: > 128 row extras per band, > 7 per node (generic path)
+    dict(skip_frac=0.4, skip_span=3, skip_max=2),             # only near predecessors (distance 2 and 3): the register window alone
+    dict(skip_frac=0.95, skip_max=9, drop_chain_frac=0.0),    # dense extras: more far edges per node than the history serves (generic path)
     dict(skip_frac=0.1, skip_span=70, repeat_frac=0.03, repeat_span=90),   # far edges: beyond the LDS history and the traceback tile
-])
-def test_random_jobs_bit_exact(ctx, kw):
+    dict(skip_frac=0.25, skip_span=27, skip_max=2),           # distances up to the on-chip limit: deepest history (64 steps), virtual lanes
+]
+
+
+@pytest.mark.parametrize("dim", [20, 61])
+@pytest.mark.parametrize("kw", FAMILIES)
+def test_random_jobs_bit_exact(ctx, kw, dim):
     from prographmsa_amd import jobs as J
     sizes = [(2, 2), (3, 2), (2, 5), (3, 3), (7, 4), (40, 33), (64, 64), (65, 66), (66, 65), (130, 97), (200, 310), (517, 129)]
-    js = [J.random_job(1000 + i, n1, n2, **kw) for i, (n1, n2) in enumerate(sizes)]
+    if dim == 61:   # the 61-state alphabet (codons): fewer sizes, same families incl. skip and repeat edges
+        sizes = [(3, 2), (7, 4), (65, 66), (130, 97), (200, 310)]
+    js = [J.random_job(1000 + i, n1, n2, dim=dim, **kw) for i, (n1, n2) in enumerate(sizes)]
     b = J.Batch(ctx, js)
     b.run()
     res = b.fetch()
@@ -53,6 +61,49 @@ def test_one_call_entry_point(ctx):
         ref = oracle_lib.align_graphs(j)
         assert np.array_equal(r["map1"], ref["map1"]) and np.array_equal(r["map2"], ref["map2"])
         assert np.float32(r["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
+
+
+def test_invalid_graphs_are_rejected(ctx):
+    """PGM_ERR_INVALID: an edge to a later node (Graph.h:43 guarantees from < to) and a dimension mismatch."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    good = J.random_job(5, 30, 28, skip_frac=0.2)
+    bad = J.random_job(6, 30, 28, skip_frac=0.2)
+    bad.g1.e_col[int(bad.g1.e_rowptr[10])] = 17          # node 10 <- node 17
+    cj = J.CJobs([good, bad])
+    rc = pg.lib.pgm_align_graphs_batch(ctx.handle, cj.n, cj.g1, cj.g2, cj.m, cj.sc, cj.out)
+    assert rc == pg.PGM_ERR_INVALID and b"job 1" in pg.lib.pgm_last_error()
+    mism = J.random_job(7, 30, 28, skip_frac=0.2)
+    other = J.random_job(8, 30, 28, dim=61, skip_frac=0.2)
+    mism.g2 = other.g2                                    # 20-state graph against a 61-state graph
+    cj = J.CJobs([mism])
+    rc = pg.lib.pgm_align_graphs_batch(ctx.handle, cj.n, cj.g1, cj.g2, cj.m, cj.sc, cj.out)
+    assert rc == pg.PGM_ERR_INVALID
+    # the context is still usable afterwards
+    assert J.align_graphs_batch(ctx, [good])[0]["status"] == 0
+
+
+def test_handoff_timeout_aborts_the_batch(ctx, monkeypatch):
+    """PGM_ERR_DEVICE: band 0 of job 0 never publishes its progress (test knob), the band below times out after a
+    shortened spin limit, raises the abort flag and every job of the batch reports a device error instead of hanging."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    js = [J.random_job(21, 200, 150, skip_frac=0.2), J.random_job(22, 90, 80, skip_frac=0.0, drop_chain_frac=0.0)]
+    b = J.Batch(ctx, js)
+    monkeypatch.setenv("PGM_TEST_SPIN_LIMIT", "2000")
+    monkeypatch.setenv("PGM_TEST_STALL", "0:0")
+    b.run()
+    rc = pg.lib.pgm_align_batch_fetch(ctx.handle, b.handle, b.cj.out)
+    assert rc == pg.PGM_ERR_DEVICE and b"timed out" in pg.lib.pgm_last_error()
+    monkeypatch.delenv("PGM_TEST_SPIN_LIMIT")
+    monkeypatch.delenv("PGM_TEST_STALL")
+    b.run()                                               # the same batch runs clean afterwards
+    res = b.fetch()
+    import oracle_lib
+    for j, r in zip(js, res):
+        ref = oracle_lib.align_graphs(j)
+        assert r["status"] == 0 and np.array_equal(r["map1"], ref["map1"]) and np.array_equal(r["map2"], ref["map2"])
+    b.close()
 
 
 def test_empty_batch(ctx):

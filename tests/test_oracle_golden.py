@@ -101,6 +101,30 @@ def test_c3_256x1000_md5(oracle_build, tmp_path):
     assert hashlib.md5(out.encode()).hexdigest() == md5["c3.out.fa"]
 
 
+def test_c4_128x1000_codons_md5(oracle_build, tmp_path):
+    """BASELINE config 4 at full size (128 x 1000 codons, --codon, one pass on the reference's guide tree): ~20 s of oracle."""
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    (tmp_path / "c4.fa").write_text(gen.fasta(gen.gen_codon(128, 1000, 4)))
+    out = run_oracle(oracle_build, ["--codon", "--fasta", "-t", os.path.join(GOLD, "c4.tree"), str(tmp_path / "c4.fa")])
+    assert hashlib.md5(out.encode()).hexdigest() == md5["c4.out.fa"]
+
+
+@pytest.mark.parametrize("cs", [False, True])
+def test_c5_1024x600_md5(oracle_build, tmp_path, cs):
+    """BASELINE config 5 at full size (1024 x 600 aa, one pass): ~30 s of oracle; with the synthetic K = 4000 library
+    (createProfile of 1024 leaves: ~2 min of oracle) only when PGM_SLOW_TESTS=1."""
+    if cs and os.environ.get("PGM_SLOW_TESTS") != "1":
+        pytest.skip("2 minutes of CPU: set PGM_SLOW_TESTS=1 (verified in round 2: md5 8c4438f7... identical to the reference binary)")
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    (tmp_path / "c5.fa").write_text(gen.fasta(gen.gen(1024, 600, 6)))
+    args = ["--fasta", "-t", os.path.join(GOLD, "c5.tree")]
+    if cs:
+        (tmp_path / "K4000syn.lib").write_text(gen.genlib(4000, 11))
+        args += ["--cs_profile", str(tmp_path / "K4000syn.lib")]
+    out = run_oracle(oracle_build, args + [str(tmp_path / "c5.fa")])
+    assert hashlib.md5(out.encode()).hexdigest() == md5["c5.cs.out.fa" if cs else "c5.out.fa"]
+
+
 @pytest.mark.parametrize("case", ["cd1", "cd2"])
 def test_codon_fasta_identical_to_reference(oracle_build, case):
     """--codon: 61-state ECM model, codon alphabet (BASELINE config 4 in small)."""

@@ -38,7 +38,7 @@ for q in (0.5, 0.75, 0.9, 0.95, 0.99, 1.0):
 late = np.argsort(-end)[:12]
 for i in late:
     j, bd = items[i]
-    print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 47) // 48, start[i], bend[i], tend[i]))
+    print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 63) // 64, start[i], bend[i], tend[i]))
 tbi = np.where(tend > 0)[0]
 rel = (raw[tbi, 4] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
 stg = (raw[tbi, 4] >> np.uint64(32)).astype(np.float64) / 100.0   # of which: loads -> LDS (the rest is the link pass)
@@ -53,6 +53,15 @@ for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs
 ri = [k for k, i in enumerate(tbi) if items[i, 0] == np.argmax(sizes[:, 0] * sizes[:, 1])][0]
 print("root traceback: %.0f us, tile staging %.0f us (loads -> LDS %.0f us, links %.0f us) in %.0f tiles (%.1f us/tile), slow steps %.0f" % (tb[tbi][ri], rel[ri], stg[ri], rel[ri] - stg[ri], nrel[ri], rel[ri] / nrel[ri], slow[ri]))
 print("all merged: loads -> LDS %.1f us/tile, links %.1f us/tile; chain-only: %.1f / %.1f" % ((stg[~m] / nrel[~m]).mean(), ((rel[~m] - stg[~m]) / nrel[~m]).mean(), (stg[m] / nrel[m]).mean(), ((rel[m] - stg[m]) / nrel[m]).mean()))
+# step time per class of job: (band end - start - wait) / (steps of the item's last band + its start offset)
+cnt = np.frombuffer(buf, np.uint32, 4 * n, 4).reshape(n, 4)[:, 3]
+ext = np.array([int(j.g1.e_col.size != j.g1.n - 1 or j.g2.e_col.size != j.g2.n - 1) for j in jobs])
+steps = np.array([sizes[items[i, 0]][1] - 1 + 63 for i in range(n)], dtype=np.float64)
+per = (bend - start - wait_us) / steps
+for nm, mm in (("chain-only items", ext[items[:, 0]] == 0), ("merged items", ext[items[:, 0]] == 1), ("root items", items[:, 0] == np.argmax(sizes[:, 0] * sizes[:, 1]))):
+    if mm.any():
+        print("%-18s: %4d items, bands/item %.2f, (band end - start - wait of wavefront 0) / steps: mean %.3f us, median %.3f, p90 %.3f; wait mean %.0f us" % (
+            nm, mm.sum(), cnt[mm].mean(), per[mm].mean(), np.median(per[mm]), np.quantile(per[mm], 0.9), wait_us[mm].mean()))
 # per-job: first start, last end
 for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
