@@ -241,9 +241,10 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     }
 }
 
-// wave-uniform maximum of a per-lane value in 0..7 (three ballots, no cross-lane data movement)
+// wave-uniform maximum of a per-lane value in 0..15 (four ballots, no cross-lane data movement)
 __device__ __forceinline__ int pgm_wave_max8(uint32_t v) {
-    int m = __builtin_amdgcn_ballot_w64(v >= 4u) != 0 ? 4 : 0;
+    int m = __builtin_amdgcn_ballot_w64(v >= 8u) != 0 ? 8 : 0;
+    m += __builtin_amdgcn_ballot_w64(v >= (uint32_t)(m + 4)) != 0 ? 4 : 0;
     m += __builtin_amdgcn_ballot_w64(v >= (uint32_t)(m + 2)) != 0 ? 2 : 0;
     m += __builtin_amdgcn_ballot_w64(v >= (uint32_t)(m + 1)) != 0 ? 1 : 0;
     return m;
@@ -868,14 +869,24 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 //       from the cell storage through the CSR lists (device-scope loads), as rare as pathological graphs are.
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b that are
 // complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
-template <bool NEAR>
+// MODE 0: chain-only job (every node has at most its chain predecessor): chain terms only, no history of the band's own rows
+// MODE 1: merged graphs, self-contained: near window + far history + generic path in this wavefront
+// MODE 2: merged graphs on the batch's critical path (PgmJob::mode2): this wavefront only evaluates the two terms that
+//         depend on the previous step (chain X, chain Y), merges the partial maxima three helper wavefronts have
+//         prepared a step ahead (pgm_terms_helper), stores the cell and records W, Y, X in the history
+template <int MODE>
 __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *abort_flag, bool &aborted,
-                                               const uint32_t spin_limit, const bool stall, unsigned long long *wait_acc) {
+                                               const uint32_t spin_limit, const bool stall, unsigned long long *wait_acc, int *sw_generic, const uint32_t dbg_flags) {
+    constexpr bool NEAR = MODE == 1, HELPED = MODE == 2, EXTRAS = MODE != 0;
     constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF;
+    constexpr int RS = HELPED ? 5 : 3;   // float4 per column of the ring: {q0, fd0-3, fc0-3}, or the whole node summary for the far helper
+    typedef __attribute__((address_space(3))) int pgm_lds_int;
+    pgm_lds_int *sw = (pgm_lds_int *)sw_generic;   // LDS pointer: a generic one would make every access a flat one (waits for vmcnt too)
     const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
     const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
     const uint32_t D = J.hD, Dm = D - 1u, DX = J.hDX, DXm = DX - 1u;
-    const bool has_far = NEAR && J.has_far != 0;
+    const bool has_far = EXTRAS && J.has_far != 0;
+    const bool record = HELPED || has_far;   // the band's own W, Y, X go into the history
     // LDS of this sweep: W / Y history [D][80] (columns 0..15: virtual lanes), X history [DX][64], column summaries [128][3]
     float *hW = (float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
     float4 *ring3 = (float4 *)(hX + DX * 64u);
@@ -883,12 +894,12 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     const bool rowvalid = y + 1 < n1;
     const uint32_t yc = rowvalid ? y : 0u;
     const float4 *niq = (const float4 *)(J.ni1 + yc);
-    const float4 r0 = pgm_gload4(niq), r1 = pgm_gload4(niq + 1), r2 = pgm_gload4(niq + 2);
+    const float4 r0 = pgm_gload4(niq), r1 = pgm_gload4(niq + 1), r2 = pgm_gload4(niq + 3);
     const float ccy = r0.x;
     const uint32_t fy = rowvalid ? __float_as_uint(r0.w) : 0u;
-    const bool geny = NEAR && ((fy & 8u) != 0 || ((fy & 7u) != 0 && ((fy >> 8) & 255u) > (uint32_t)(lane + VL)));
-    const bool ykill = (fy & 16u) != 0;
-    const float c2y = (NEAR && !geny) ? r0.y : INFINITY, c3y = (NEAR && !geny) ? r0.z : INFINITY;
+    const bool geny = EXTRAS && ((fy & PGM_NF_GENERIC) != 0 || ((fy & PGM_NF_COUNT) != 0 && ((fy >> 8) & 255u) > (uint32_t)(lane + VL)));
+    const bool ykill = (fy & PGM_NF_KILL) != 0;
+    const float c2y = (EXTRAS && !geny) ? r0.y : INFINITY, c3y = (NEAR && !geny) ? r0.z : INFINITY;
     uint32_t fdy[KF];
     float fcy[KF];
     {
@@ -899,7 +910,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             fcy[k] = (NEAR && rowvalid && !geny) ? csrc[k] : INFINITY;
         }
     }
-    const int nfyw = NEAR ? pgm_wave_max8(geny ? 0u : (fy & 7u)) : 0;
+    const int nfyw = NEAR ? pgm_wave_max8(geny ? 0u : (fy & PGM_NF_COUNT)) : 0;
     const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
     const float gopen_x = (rowvalid && y == 0) ? sg : gi;
     const bool has_next = (b + 1 < nb), has_prev = (b > 0);
@@ -909,32 +920,32 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
     const float4 *ni2q = (const float4 *)J.ni2;
     const uint32_t lb = (uint32_t)(VL + lane);
+    const float *resA = (const float *)(slot + J.aux_off + PGM_AUX_RES), *resB = resA + 768, *resC = resA + 1536;
+    const bool use_far = has_far && !(dbg_flags & 16u);
+    int seenA = (dbg_flags & 32u) ? 0x7fffffff : 0, seenB = use_far ? 0 : 0x7fffffff, seenC = seenB;   // HELPED: steps whose terms the helpers have published
 
     for (uint32_t i = (uint32_t)lane; i < D * HS; i += 64u) { hW[i] = PGM_NEG_INF; hY[i] = PGM_NEG_INF; }
     for (uint32_t i = (uint32_t)lane; i < DX * 64u; i += 64u) hX[i] = PGM_NEG_INF;
-    for (int i = lane; i < NR * 3; i += 64) ring3[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // "column < 0" slots
+    for (int i = lane; i < NR * RS; i += 64) ring3[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // "column < 0" slots
 
     // ---- block prefetch (global -> registers a block ahead -> LDS / registers of the block) ------------------------
     float4 pfq, pfs[BL / 4];
     float2 pfr[2];
-    const int rq_col = lane / 3, rq_part = lane % 3;   // lanes 0..23: one float4 of the 8 column summaries of a block
+    const int rq_col = lane / RS, rq_part = lane % RS;   // lanes 0..8 RS - 1: one float4 of the 8 column summaries of a block
+    const int rq_quad = (RS == 3 && rq_part == 2) ? 3 : rq_part;   // which float4 of the 5 of a node summary
     auto load_ring_block = [&](uint32_t c0) {
         const uint32_t col = c0 + (uint32_t)rq_col;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane < 3 * BL && col <= ncol) v = pgm_gload4(ni2q + 3u * col + (uint32_t)rq_part);
+        if (lane < RS * BL && col <= ncol) v = pgm_gload4(ni2q + 5u * col + (uint32_t)rq_quad);
         pfq = v;
     };
     auto store_ring_block = [&](uint32_t c0) {
-        if (lane < 3 * BL) ring3[((c0 + (uint32_t)rq_col) & (uint32_t)(NR - 1)) * 3u + (uint32_t)rq_part] = pfq;
+        if (lane < RS * BL) ring3[((c0 + (uint32_t)rq_col) & (uint32_t)(NR - 1)) * (uint32_t)RS + (uint32_t)rq_part] = pfq;
     };
     auto load_s_block = [&](uint32_t s0) {
-        const uint32_t tb = s0 / BL;
+        const uint32_t tb = min(s0 / BL, nblk - 1u);   // (a block beyond the sweep is never consumed: any valid address will do)
 #pragma unroll
-        for (int q = 0; q < BL / 4; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tb < nblk) v = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
-            pfs[q] = v;
-        }
+        for (int q = 0; q < BL / 4; ++q) pfs[q] = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
     };
     // virtual lanes of my steps s0 .. s0+7: virtual lane v (= lane v - 16, i.e. row 64 b - 16 + v) at my step s is the cell
     // lane 48 + v of band b-1 produced at ITS step s + 64 (column s + 16 - v); cells outside the matrix read as -inf
@@ -973,7 +984,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                     break;
                 }
             }
-            if (w0) *wait_acc += __builtin_amdgcn_s_memrealtime() - w0;
+            if (w0) wait_acc[0] += __builtin_amdgcn_s_memrealtime() - w0;
         }
     };
     // split-phase poll: the progress word is read one block ahead (no round trip on the band's own critical path);
@@ -999,13 +1010,23 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     load_ring_block(2 * BL);
     load_rep_block(BL);
     poll_issue();
+    if (HELPED) {   // history initialised, first blocks staged: the helpers may start (sw[0] = last recorded step + 2)
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(sw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     // ---- the sweep ---------------------------------------------------------------------------------------------------
     float u1W[4], u2W[4], u3W[4], ow[4], ox[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { u1W[k] = PGM_NEG_INF; u2W[k] = PGM_NEG_INF; u3W[k] = PGM_NEG_INF; ow[k] = PGM_NEG_INF; ox[k] = PGM_NEG_INF; }
     float u1Y = PGM_NEG_INF, u2Y = PGM_NEG_INF, u3Y = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
-    for (uint32_t t0 = 0; t0 < tsteps && !aborted; t0 += BL) {
+    // LDS operands of a step are read one step ahead: the column summary and lane 0's upper neighbours (virtual lanes of the
+    // history; all lanes read the same word, only lane 0 keeps it: `old` operand of the DPP shift)
+    float4 cn_n = ring3[(((uint32_t)(-lane)) & (uint32_t)(NR - 1)) * (uint32_t)RS];
+    float inW1 = hW[(0xFFFFFFFFu & Dm) * HS + VL - 1], inY1 = hY[(0xFFFFFFFFu & Dm) * HS + VL - 1];
+    float inW2 = hW[(0xFFFFFFFEu & Dm) * HS + VL - 2], inY2 = hY[(0xFFFFFFFEu & Dm) * HS + VL - 2];
+    float inW3 = hW[(0xFFFFFFFDu & Dm) * HS + VL - 3], inY3 = hY[(0xFFFFFFFDu & Dm) * HS + VL - 3];
+    for (uint32_t t0 = 0; !aborted; t0 += BL) {
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const uint32_t t = t0 + i;
@@ -1013,35 +1034,80 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             const bool incol = xs >= 0 && xs < (int)ncol;
             const bool active = rowvalid && incol;
             const uint32_t x = (uint32_t)xs;
-            const uint32_t rslot = (x & (uint32_t)(NR - 1)) * 3u;
-            const float4 cn = ring3[rslot];
-            const float ccx = cn.x, c2x = NEAR ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
+            const uint32_t rslot = (x & (uint32_t)(NR - 1)) * (uint32_t)RS;
+            const float4 cn = cn_n;
+            const float iW1 = inW1, iY1 = inY1, iW2 = inW2, iY2 = inY2, iW3 = inW3, iY3 = inY3;
+            float hM = PGM_NEG_INF, hX_ = PGM_NEG_INF, hY_ = PGM_NEG_INF;
+            if (HELPED && !(dbg_flags & 2u)) {
+                // partial maxima of the helper wavefronts for this step (they run ahead: normally no wait).  The reads are issued
+                // here, together with the other LDS operands, and consumed after the chain terms.
+                const int want = (int)t + 1;
+                if (seenA < want || seenB < want || seenC < want) {
+                    uint32_t spins = 0;
+                    const unsigned long long h0 = wait_acc ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    for (;;) {
+                        if (!(dbg_flags & 32u)) seenA = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        if (use_far) {
+                            seenB = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            seenC = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        }
+                        if (seenA >= want && seenB >= want && seenC >= want) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
+                    }
+                    if (wait_acc) wait_acc[1] += __builtin_amdgcn_s_memrealtime() - h0;
+                }
+                asm volatile("" ::: "memory");
+                const uint32_t ro = (t & 3u) * 192u + (uint32_t)lane;
+                if (!(dbg_flags & 32u)) { hM = resA[ro]; hX_ = resA[ro + 64]; hY_ = resA[ro + 128]; }
+                if (use_far) {
+                    hM = fmaxf(hM, fmaxf(resB[ro], resC[ro]));
+                    hX_ = fmaxf(hX_, resB[ro + 64]);
+                    hY_ = fmaxf(hY_, resC[ro + 128]);
+                }
+            }
+            {   // operands of step t + 1 (their virtual-lane entries and column summaries were staged at least a block ago)
+                cn_n = ring3[((x + 1u) & (uint32_t)(NR - 1)) * (uint32_t)RS];
+                const uint32_t tm0 = (t & Dm) * HS, tm1 = ((t - 1u) & Dm) * HS, tm2 = ((t - 2u) & Dm) * HS;
+                inW1 = hW[tm0 + VL - 1]; inY1 = hY[tm0 + VL - 1];
+                if (EXTRAS) { inW2 = hW[tm1 + VL - 2]; inY2 = hY[tm1 + VL - 2]; }
+                if (NEAR) { inW3 = hW[tm2 + VL - 3]; inY3 = hY[tm2 + VL - 3]; }
+            }
+            const float ccx = cn.x, c2x = EXTRAS ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
             const uint32_t fx = __float_as_uint(cn.w);
-            const bool genx = NEAR && active && (fx & 8u) != 0;
-            const bool xkill = active && (fx & 16u) != 0;
+            const bool genx = EXTRAS && active && (fx & PGM_NF_GENERIC) != 0;
+            const bool xkill = active && (fx & PGM_NF_KILL) != 0;
             const float gopen_y = (xs == 0) ? sg : gi;
             const float S = Sc[i];
-            // the rows above: lane 0's upper neighbours come from the virtual lanes of the history (all lanes read the same
-            // word, only lane 0 keeps it: `old` operand of the DPP shift)
-            const uint32_t tm1 = ((t - 1u) & Dm) * HS, tm2 = ((t - 2u) & Dm) * HS, tm3 = ((t - 3u) & Dm) * HS;
             const int s0 = i & 3, sm1 = (i + 3) & 3, sm2 = (i + 2) & 3, sm3 = (i + 1) & 3;
             if (NEAR) {
-                const float iW3 = hW[tm3 + VL - 3], iY3 = hY[tm3 + VL - 3], iW2 = hW[tm2 + VL - 2], iY2 = hY[tm2 + VL - 2];
-                const float n3W = pgm_dpp_wave_shr1(u2W[sm1], iW3), n2W = pgm_dpp_wave_shr1(u1W[sm1], iW2);
-                const float n3Y = pgm_dpp_wave_shr1(u2Y, iY3), n2Y = pgm_dpp_wave_shr1(u1Y, iY2);
-                u3W[s0] = n3W; u2W[s0] = n2W; u3Y = n3Y; u2Y = n2Y;
+                const float n3W = pgm_dpp_wave_shr1(u2W[sm1], iW3), n3Y = pgm_dpp_wave_shr1(u2Y, iY3);
+                u3W[s0] = n3W; u3Y = n3Y;
             }
-            {
-                const float iW1 = hW[tm1 + VL - 1], iY1 = hY[tm1 + VL - 1];
-                u1W[s0] = pgm_dpp_wave_shr1(W_o, iW1);
-                u1Y = pgm_dpp_wave_shr1(Y_o, iY1);
+            if (EXTRAS) {
+                const float n2W = pgm_dpp_wave_shr1(u1W[sm1], iW2), n2Y = pgm_dpp_wave_shr1(u1Y, iY2);
+                u2W[s0] = n2W; u2Y = n2Y;
             }
+            u1W[s0] = pgm_dpp_wave_shr1(W_o, iW1);
+            u1Y = pgm_dpp_wave_shr1(Y_o, iY1);
             auto mterm = [&](float w, float cy, float cx) { return __fsub_rn(__fsub_rn(__fadd_rn(w, S), cy), cx); };
             auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
             auto yterm = [&](float yp, float wp, float cy) { return __fsub_rn(fmaxf(__fadd_rn(yp, ge), __fadd_rn(wp, gopen_y)), cy); };
             float Mv = mterm(u1W[sm1], ccy, ccx);
             float Xv = xterm(ox[sm1], ow[sm1], ccx);
             float Yv = yterm(u1Y, u1W[s0], ccy);
+            if (HELPED) {
+                // the terms that read step t - 2 are evaluated here too (X from column x-2, Y from row y-2: own registers); every
+                // other term of this step only needs the history up to step t - 3 and comes from the helper wavefronts: the other
+                // near terms (A), the far edges of the columns (B), the far edges of the rows (C)
+                Xv = fmaxf(Xv, xterm(ox[sm2], ow[sm2], c2x));
+                Yv = fmaxf(Yv, yterm(u2Y, u2W[s0], c2y));
+            }
+            if (HELPED && !(dbg_flags & 2u)) {
+                Mv = fmaxf(Mv, hM);
+                Xv = fmaxf(Xv, hX_);
+                Yv = fmaxf(Yv, hY_);
+            }
             if (NEAR) {
                 Mv = fmaxf(Mv, fmaxf(mterm(u1W[sm2], ccy, c2x), mterm(u1W[sm3], ccy, c3x)));
                 Mv = fmaxf(Mv, fmaxf(mterm(u2W[sm1], c2y, ccx), fmaxf(mterm(u2W[sm2], c2y, c2x), mterm(u2W[sm3], c2y, c3x))));
@@ -1049,7 +1115,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 Xv = fmaxf(Xv, fmaxf(xterm(ox[sm2], ow[sm2], c2x), xterm(ox[sm3], ow[sm3], c3x)));
                 Yv = fmaxf(Yv, fmaxf(yterm(u2Y, u2W[s0], c2y), yterm(u3Y, u3W[s0], c3y)));
                 // ---- far edges: LDS history ----
-                const uint32_t nfx = fx & 7u;
+                const uint32_t nfx = fx & PGM_NF_COUNT;
                 if (__builtin_expect(nfyw != 0 || __builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull, 0)) {
                     const float4 f1 = ring3[rslot + 1u], f2 = ring3[rslot + 2u];
                     const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w)};
@@ -1083,6 +1149,8 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                         }
                     }
                 }
+            }
+            if (EXTRAS) {
                 // ---- generic nodes: every non-chain predecessor through the CSR lists and the cell storage ----
                 const bool gen = active && (geny || genx);
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(gen) != 0ull, 0)) {
@@ -1123,12 +1191,16 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
             if (rowvalid && y == 0 && xs == 0) Wv = s_init;
             if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
-            pgm_store_cell_masked(cells_rsrc, t, lane, active, Mv, Xv, Wv, Yv);
-            if (has_far) {
+            pgm_store_cell_masked(cells_rsrc, t, lane, active && !(dbg_flags & 1u), Mv, Xv, Wv, Yv);
+            if (record && !(dbg_flags & 8u)) {
                 const uint32_t ho = (t & Dm) * HS + lb;
                 hW[ho] = Wv;
                 hY[ho] = Yv;
                 hX[(t & DXm) * 64u + (uint32_t)lane] = Xv;
+                if (HELPED) {   // (LDS operations of a wavefront execute in order: the word follows the three stores)
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(sw, (int)t + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             W_o = Wv;
             Y_o = Yv;
@@ -1142,33 +1214,229 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
         // Stage the next blocks.  This sits at the END of the iteration so that, on every path into it, exactly the BL
         // cell stores of this block were issued after the prefetch loads consumed here: the compiler then waits for them
         // with vmcnt(BL) instead of vmcnt(0), i.e. the wavefront never drains the stores it has just issued.
+        // (the loop is left BEFORE the staging, so that the registers the prefetch loads write are the ones the next iteration
+        // reads: a path around the staging would merge at the loop head and the merge copies would wait for the loads)
         const uint32_t t1 = t0 + BL;
-        if (t1 < tsteps) {
-            store_ring_block(t1 + BL);     // one block before use
+        if (t1 >= tsteps) break;
+        store_ring_block(t1 + BL);     // one block before use
 #pragma unroll
-            for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
-            store_rep_block((int)t1);
-            load_ring_block(t1 + 2 * BL);
-            load_s_block(t1 + BL);
-            poll_collect();
-            wait_prev(t1 + BL + BL + 64);
-            load_rep_block((int)(t1 + BL));
-            poll_issue();
-        }
+        for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
+        store_rep_block((int)t1);
+        load_ring_block(t1 + 2 * BL);
+        load_s_block(t1 + BL);
+        poll_collect();
+        wait_prev(t1 + BL + BL + 64);
+        load_rep_block((int)(t1 + BL));
+        poll_issue();
     }
+    if (HELPED) __hip_atomic_store(sw, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the helpers (also after an abort)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && !stall) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Helper wavefronts of a MODE 2 sweep (PgmJob::mode2).  The sweeping wavefront keeps the terms that read steps t - 1 and
+// t - 2 (chain M, X, Y; X from column x-2, Y from row y-2).  Every other term of step t reads the history no later than
+// step t - 3, so three helper wavefronts evaluate them up to two steps ahead of the sweep (their latency is off its
+// critical path as long as their throughput keeps up), each leaving its partial maxima per lane in its own ring res[t & 3]:
+//   GROUP 0  the other near terms: eight M pairs (rows y-1..y-3 x columns x-1..x-3 without the chain pair), X from column
+//            x-3, Y from row y-3; one row per lane like the sweep
+//   GROUP 1  the far edges of the COLUMNS, one row per lane (a column's far edges pass down the lanes one step at a time):
+//            X term, M terms with the three near rows; loop to the wavefront's largest count
+//   GROUP 2  the far edges of the ROWS, one (row, far edge) ENTRY per lane — a band has a handful of them, a lane per row
+//            would loop to the largest count per row for all 64 rows: Y term, M terms with the three near columns and with
+//            the far edges of the entry's current column; merged per owner row with LDS float-max atomics (exact, order free)
+// (groups 1 and 2 may run up to far_slack steps ahead of what is recorded.)  The wavefronts only meet through LDS words:
+// sw[0] = last step the sweeping wavefront has recorded + 2 (1 = its prologue is done), sw[1 + GROUP] = number of steps
+// whose terms are published.
+template <int GROUP>
+__device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic) {
+    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5;
+    typedef __attribute__((address_space(3))) int pgm_lds_int;
+    pgm_lds_int *sw = (pgm_lds_int *)sw_generic;
+    const uint32_t n1 = J.n1, tsteps = J.tsteps, nblk = J.nblk;
+    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap;
+    const uint32_t D = J.hD, Dm = D - 1u, DX = J.hDX, DXm = DX - 1u;
+    const float *hW = (const float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
+    const float4 *ring3 = (const float4 *)(hX + DX * 64u);
+    uint8_t *aux = slot + J.aux_off;
+    float *res = (float *)(aux + PGM_AUX_RES) + GROUP * 768, *sblk = (float *)(aux + PGM_AUX_SBLK);
+    uint2 *elist = (uint2 *)(aux + PGM_AUX_EL);
+    int *ecnt = (int *)(aux + PGM_AUX_CNT);
+    const int slack = GROUP == 0 ? 3 : (int)J.far_slack;
+    const uint32_t y = 64u * b + (uint32_t)lane;
+    const bool rowvalid = y + 1 < n1;
+    const uint32_t yc = rowvalid ? y : 0u;
+    const float4 *niq = (const float4 *)(J.ni1 + yc);
+    const float4 r0 = pgm_gload4(niq), r1 = pgm_gload4(niq + 1), r1b = pgm_gload4(niq + 2), r2 = pgm_gload4(niq + 3), r2b = pgm_gload4(niq + 4);
+    const float ccy = r0.x;
+    const uint32_t fy = rowvalid ? __float_as_uint(r0.w) : 0u;
+    const bool geny = (fy & PGM_NF_GENERIC) != 0 || ((fy & PGM_NF_COUNT) != 0 && ((fy >> 8) & 255u) > (uint32_t)(lane + VL));
+    const float c2y = !geny ? r0.y : INFINITY, c3y = !geny ? r0.z : INFINITY;
+    const float gopen_x = (rowvalid && y == 0) ? sg : gi;
+    const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
+    const uint32_t lb = (uint32_t)(VL + lane);
+    // GROUP 2: entry list of the band (order irrelevant).  LDS operations of one wavefront execute in order.
+    int ne = 0;
+    uint32_t e_o[KF], e_dy[KF];
+    float e_cy[KF];
+    bool e_ok[KF];
+    if (GROUP == 2) {
+        __hip_atomic_store(ecnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t cnt = (rowvalid && !geny) ? (fy & PGM_NF_COUNT) : 0u;
+        uint32_t base = 0;
+        if (cnt) base = (uint32_t)__hip_atomic_fetch_add(ecnt, (int)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const float dsrc[KF] = {r1.x, r1.y, r1.z, r1.w, r1b.x, r1b.y, r1b.z, r1b.w}, csrc[KF] = {r2.x, r2.y, r2.z, r2.w, r2b.x, r2b.y, r2b.z, r2b.w};
+#pragma unroll
+        for (int k = 0; k < KF; ++k)
+            if ((uint32_t)k < cnt) elist[base + k] = make_uint2((uint32_t)lane | (__float_as_uint(dsrc[k]) << 8), __float_as_uint(csrc[k]));
+        ne = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#pragma unroll
+        for (int p = 0; p < KF; ++p) {
+            const int idx = p * 64 + lane;
+            e_ok[p] = idx < ne;
+            const uint2 a = e_ok[p] ? elist[idx] : make_uint2((uint32_t)lane, __float_as_uint(INFINITY));
+            e_o[p] = a.x & 255u; e_dy[p] = a.x >> 8; e_cy[p] = __uint_as_float(a.y);
+        }
+    }
+    const int npass = (ne + 63) / 64;
+    float4 pfs[BL / 4];
+    auto load_s_block = [&](uint32_t s0) {
+        const uint32_t tb = min(s0 / BL, nblk - 1u);
+#pragma unroll
+        for (int q = 0; q < BL / 4; ++q) pfs[q] = pgm_gload4(S_band + ((size_t)tb * 64u + (uint32_t)lane) * (BL / 4) + q);
+    };
+    load_s_block(0);
+    int seen = 0;
+    for (uint32_t t0 = 0; t0 < tsteps; t0 += BL) {
+        float Sc[BL];
+#pragma unroll
+        for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
+        if (GROUP == 2) {
+#pragma unroll
+            for (int i = 0; i < BL; ++i) sblk[i * 64 + lane] = Sc[i];
+        }
+        load_s_block(t0 + BL);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const uint32_t t = t0 + (uint32_t)i;
+            const int need = max(1, (int)t - slack + 2);
+            while (seen < need) {   // (a sleeping poll: a tight one would keep the CU's LDS pipeline and this SIMD's issue slots busy)
+                seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (seen < need) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            const int xs = (int)t - lane;
+            const uint32_t rslot = (((uint32_t)xs) & (uint32_t)(NR - 1)) * (uint32_t)RS;
+            const float4 cn = ring3[rslot];
+            float *rs = res + (t & 3u) * 192u;
+            if (GROUP == 0) {
+                const float S = Sc[i];
+                const float gopen_y = (xs == 0) ? sg : gi;
+                const float cy[3] = {ccy, c2y, c3y}, cx[3] = {cn.x, cn.y, cn.z};
+                float w[3][3];
+#pragma unroll
+                for (int dy = 1; dy <= 3; ++dy)
+#pragma unroll
+                    for (int dx = 1; dx <= 3; ++dx)
+                        if (dy + dx > 2) w[dy - 1][dx - 1] = hW[((t - (uint32_t)(dy + dx)) & Dm) * HS + lb - (uint32_t)dy];
+                const uint32_t s3 = t - 3u;
+                const float X3 = hX[(s3 & DXm) * 64u + (uint32_t)lane], Wx3 = hW[(s3 & Dm) * HS + lb];
+                const float Y3 = hY[(s3 & Dm) * HS + lb - 3u], Wy3 = hW[(s3 & Dm) * HS + lb - 3u];
+                float Mn = PGM_NEG_INF;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        if (dy + dx > 0) Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(w[dy][dx], S), cy[dy]), cx[dx]));
+                rs[lane] = Mn;
+                rs[64 + lane] = __fsub_rn(fmaxf(__fadd_rn(X3, ge), __fadd_rn(Wx3, gopen_x)), cn.z);
+                rs[128 + lane] = __fsub_rn(fmaxf(__fadd_rn(Y3, ge), __fadd_rn(Wy3, gopen_y)), c3y);
+            } else if (GROUP == 1) {
+                const float S = Sc[i];
+                auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
+                // ---- column entries, one row per lane ----
+                const uint32_t nfx = __float_as_uint(cn.w) & PGM_NF_COUNT;
+                float Mf = PGM_NEG_INF, Xf = PGM_NEG_INF;
+                if (__builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull) {
+                    const int nfxw = pgm_wave_max8(nfx);
+                    const float4 f1 = ring3[rslot + 1u], f2 = ring3[rslot + 3u];
+                    float4 f1b = make_float4(0.f, 0.f, 0.f, 0.f), f2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                    if (nfxw > 4) { f1b = ring3[rslot + 2u]; f2b = ring3[rslot + 4u]; }
+                    const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w),
+                                              __float_as_uint(f1b.x), __float_as_uint(f1b.y), __float_as_uint(f1b.z), __float_as_uint(f1b.w)};
+                    const float fcx[KF] = {f2.x, f2.y, f2.z, f2.w, f2b.x, f2b.y, f2b.z, f2b.w};
+#pragma unroll
+                    for (int j = 0; j < KF; ++j) {
+                        if (j < nfxw) {
+                            const uint32_t s1 = t - fdx[j];
+                            const float Xh = hX[(s1 & DXm) * 64u + (uint32_t)lane], Wh = hW[(s1 & Dm) * HS + lb];
+                            const float W1 = hW[((s1 - 1u) & Dm) * HS + lb - 1u], W2 = hW[((s1 - 2u) & Dm) * HS + lb - 2u], W3 = hW[((s1 - 3u) & Dm) * HS + lb - 3u];
+                            Xf = fmaxf(Xf, xterm(Xh, Wh, fcx[j]));
+                            Mf = fmaxf(Mf, fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), fcx[j]),
+                                                 fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, S), c2y), fcx[j]), __fsub_rn(__fsub_rn(__fadd_rn(W3, S), c3y), fcx[j]))));
+                        }
+                    }
+                }
+                rs[lane] = Mf; rs[64 + lane] = Xf;
+            } else {
+                rs[lane] = PGM_NEG_INF; rs[128 + lane] = PGM_NEG_INF;
+                // ---- row entries, one entry per lane ----
+#pragma unroll
+                for (int p = 0; p < KF; ++p) {
+                    if (p < npass) {
+                        const uint32_t o = e_o[p], dy = e_dy[p];
+                        const float cy = e_cy[p];
+                        const int xo = (int)t - (int)o;
+                        const uint32_t rso = ((uint32_t)xo & (uint32_t)(NR - 1)) * (uint32_t)RS;
+                        const float4 cno = ring3[rso];
+                        const float So = sblk[i * 64 + (int)o];
+                        const float gopen_y = (xo == 0) ? sg : gi;
+                        const uint32_t s1 = t - dy, lp = (uint32_t)VL + o - dy;
+                        const float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
+                        const float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                        const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);
+                        float Mt = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, So), cy), cno.x),
+                                         fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, So), cy), cno.y), __fsub_rn(__fsub_rn(__fadd_rn(W3, So), cy), cno.z)));
+                        const uint32_t nfo = e_ok[p] ? (__float_as_uint(cno.w) & PGM_NF_COUNT) : 0u;
+                        if (__builtin_amdgcn_ballot_w64(nfo != 0u) != 0ull) {
+                            const int nw = pgm_wave_max8(nfo);
+                            const float4 g1 = ring3[rso + 1u], g2 = ring3[rso + 3u];
+                            float4 g1b = make_float4(0.f, 0.f, 0.f, 0.f), g2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                            if (nw > 4) { g1b = ring3[rso + 2u]; g2b = ring3[rso + 4u]; }
+                            const uint32_t gdx[KF] = {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w),
+                                                      __float_as_uint(g1b.x), __float_as_uint(g1b.y), __float_as_uint(g1b.z), __float_as_uint(g1b.w)};
+                            const float gcx[KF] = {g2.x, g2.y, g2.z, g2.w, g2b.x, g2b.y, g2b.z, g2b.w};
+#pragma unroll
+                            for (int j = 0; j < KF; ++j) {
+                                if (j < nw) {
+                                    const float Wp = hW[((s1 - gdx[j]) & Dm) * HS + lp];
+                                    Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), gcx[j]));
+                                }
+                            }
+                        }
+                        if (e_ok[p]) {
+                            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(rs + o), Mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(rs + 128 + o), Yt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+                        }
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(sw + 1 + GROUP, (int)t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
 }
 
 // NOTRACEBACK = true: timing build for tools (the fill alone, no traceback)
 template <bool NOTRACEBACK>
 __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace,
-                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band) {
+                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags) {
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
     // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
     __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
     __shared__ int item_lds, tb_go;
+    __shared__ int fsync[4];       // MODE 2 item: {last recorded step + 2, terms published by helper groups 0, 1, 2}
     static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
@@ -1180,6 +1448,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
+            fsync[0] = 0; fsync[1] = 0; fsync[2] = 0; fsync[3] = 0;
         }
         __syncthreads();
         const int it = item_lds;
@@ -1195,12 +1464,21 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         const uint32_t b = item.band + (uint32_t)role;
         const bool last_band = (item.band + item.count == J.nb);
         if ((uint32_t)role < item.count) {
-            unsigned long long wait_ticks = 0;
+            unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helper
             const bool stall = item.job == stall_job && b == stall_band;
             uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
-            if (J.has_extras) pgm_sweep_band<true>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? &wait_ticks : nullptr);
-            else pgm_sweep_band<false>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? &wait_ticks : nullptr);
-            if (trace && threadIdx.x == 0) trace[6 * it] |= wait_ticks << 16;   // (wavefront 0 of the worker; worker id in the low 16 bits)
+            if (J.mode2) pgm_sweep_band<2>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, fsync, dbg_flags);
+            else if (J.has_extras) pgm_sweep_band<1>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
+            else pgm_sweep_band<0>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
+            if (trace && threadIdx.x == 0) { trace[6 * it] |= wait_ticks[0] << 16; if (!last_band) trace[6 * it + 4] = wait_ticks[1]; }   // (wavefront 0 of the worker; worker id in the low 16 bits)
+        } else if (J.mode2 && !(dbg_flags & 4u)) {
+            // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts
+            __builtin_amdgcn_s_setprio(0);
+            if (role == 1) { if (!(dbg_flags & 32u)) pgm_terms_helper<0>(J, item.band, L.pool, lane, fsync); }
+            else if (J.has_far && !(dbg_flags & 16u)) {
+                if (role == 2) pgm_terms_helper<1>(J, item.band, L.pool, lane, fsync);
+                else pgm_terms_helper<2>(J, item.band, L.pool, lane, fsync);
+            }
         }
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         if (last_band) {

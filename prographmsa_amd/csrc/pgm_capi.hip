@@ -147,6 +147,8 @@ struct SideOff {
     uint32_t nodes_with_extras;   // nodes with a predecessor other than the chain neighbour
     uint32_t far_nodes;           // nodes with entries served from the LDS history
     uint32_t maxd;                // largest on-chip predecessor distance of the graph (>= 1)
+    uint32_t far_dmin;            // smallest distance of a far entry (PGM_DCAP + 1 if there is none)
+    uint32_t max_nfar;            // largest number of far entries of one node (<= PGM_KF8)
 };
 
 static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
@@ -156,12 +158,12 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
     std::vector<PgmNode2> ni(n);
-    o.nodes_with_extras = 0; o.far_nodes = 0; o.maxd = 1;
+    o.nodes_with_extras = 0; o.far_nodes = 0; o.maxd = 1; o.far_dmin = PGM_DCAP + 1; o.max_nfar = 0;
     for (uint32_t v = 0; v < n; ++v) {
         PgmNode2 &I = ni[v];
         memset(&I, 0, sizeof I);
         I.cc = I.c2 = I.c3 = INFINITY;
-        for (int k = 0; k < PGM_KF; ++k) I.fc[k] = INFINITY;
+        for (int k = 0; k < PGM_KF8; ++k) I.fc[k] = INFINITY;
         uint32_t nfar = 0, dmax = 1;
         bool generic = false;
         // near slots: the first finite-cost edge from node-1 / node-2 / node-3; everything else is a far entry (an edge of
@@ -173,7 +175,7 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
             if (val == INFINITY) return;
             if (d == 2 && I.c2 == INFINITY) { I.c2 = val; dmax = std::max(dmax, d); return; }
             if (d == 3 && I.c3 == INFINITY) { I.c3 = val; dmax = std::max(dmax, d); return; }
-            if (nfar >= (uint32_t)PGM_KF || d > (uint32_t)PGM_DCAP) { generic = true; return; }
+            if (nfar >= (uint32_t)PGM_KF8 || d > (uint32_t)PGM_DCAP) { generic = true; return; }
             I.fd[nfar] = d; I.fc[nfar] = val; ++nfar;
             dmax = std::max(dmax, d);
         };
@@ -202,14 +204,16 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
         pp[v + 1] = (int32_t)pc.size();
         if (generic) {   // every non-chain predecessor of this node goes through the CSR lists and the cell storage
             I.c2 = I.c3 = INFINITY;
-            for (int k = 0; k < PGM_KF; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
-            I.flags = 8u | (1u << 8);
+            for (int k = 0; k < PGM_KF8; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
+            I.flags = PGM_NF_GENERIC | (1u << 8);
         } else {
             I.flags = nfar | (dmax << 8);
             o.maxd = std::max(o.maxd, dmax);
             o.far_nodes += nfar != 0;
+            o.max_nfar = std::max(o.max_nfar, nfar);
+            for (uint32_t k = 0; k < nfar; ++k) o.far_dmin = std::min(o.far_dmin, I.fd[k]);
         }
-        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= 16u;  // interior node without predecessors
+        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= PGM_NF_KILL;  // interior node without predecessors
         o.nodes_with_extras += (xp[v + 1] > xp[v]);
     }
     // at least one element each so that pointers are valid
@@ -278,8 +282,11 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     uint32_t spin_limit = PGM_SPIN_LIMIT, stall_job = 0xFFFFFFFFu, stall_band = 0;
     if (const char *v = getenv("PGM_TEST_SPIN_LIMIT")) spin_limit = (uint32_t)std::max(1, atoi(v));
     if (const char *v = getenv("PGM_TEST_STALL")) { unsigned a = 0, c = 0; if (sscanf(v, "%u:%u", &a, &c) == 2) { stall_job = a; stall_band = c; } }
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band);
+    // timing experiments only (results are garbage): 1 = the cell stores are dropped, 2 = the sweeping wavefront of a MODE 2 band
+    // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
+    const uint32_t dbg_flags = getenv("PGM_TEST_NOSTORE") ? (uint32_t)atoi(getenv("PGM_TEST_NOSTORE")) : 0u;
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
@@ -363,6 +370,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     {
         std::atomic<int> bad(-1);
         std::atomic<uint32_t> next_job(0);
+        const bool no_helper = getenv("PGM_NO_HELPER") != nullptr;                                  // experiments only
+        const int mode2_min_bands = getenv("PGM_MODE2_BANDS") ? atoi(getenv("PGM_MODE2_BANDS")) : 20;   // experiments only
         auto work = [&]() {
             for (;;) {
                 const uint32_t i = next_job.fetch_add(1);
@@ -381,8 +390,30 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 while (hD < o.s1.maxd + o.s2.maxd + (uint32_t)PGM_BLOCK) hD *= 2;
                 while (hDX < o.s2.maxd + 1) hDX *= 2;
                 J.hD = hD; J.hDX = hDX;
-                J.slot_bytes = 2u * hD * (64u + PGM_VL) * 4u + hDX * 64u * 4u + PGM_NRING * 48u;
-                J.nslots = std::max(1u, std::min(4u, (uint32_t)PGM_POOL / J.slot_bytes));
+                J.slot_bytes = 2u * hD * (64u + PGM_VL) * 4u + hDX * 64u * 4u;
+                // Jobs on the batch's critical path (many bands, or a deep history that leaves room for one or two sweeps per
+                // worker anyway) are swept one band per worker: the other three wavefronts take every term but the two chain
+                // terms off the sweeping wavefront (pgm_terms_helper), which shortens its step by a factor of 2-3.
+                const uint32_t nb_job = (g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
+                J.mode2 = (J.has_extras && (hD >= 32u || nb_job >= (uint32_t)mode2_min_bands) && !no_helper) ? 1u : 0u;
+                J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
+                J.slot_bytes += PGM_NRING * (J.mode2 ? 80u : 48u);   // column ring: 5 or 3 float4 per column
+                J.aux_off = J.slot_bytes;
+                if (J.mode2) J.slot_bytes += PGM_AUX_BYTES;
+                J.nslots = J.mode2 ? 1u : std::max(1u, std::min(4u, (uint32_t)PGM_POOL / J.slot_bytes));
+                if (!J.mode2 && std::max(o.s1.max_nfar, o.s2.max_nfar) > (uint32_t)PGM_KF) {
+                    // a self-contained sweep serves PGM_KF far edges per node: nodes with more become generic
+                    for (int side = 0; side < 2; ++side) {
+                        PgmNode2 *ni = (PgmNode2 *)(b->h_in + (side ? o.s2.ni : o.s1.ni));
+                        const uint32_t nn = side ? g2[i]->n : g1[i]->n;
+                        for (uint32_t v = 0; v < nn; ++v)
+                            if ((ni[v].flags & PGM_NF_COUNT) > (uint32_t)PGM_KF && !(ni[v].flags & PGM_NF_GENERIC)) {
+                                ni[v].c2 = ni[v].c3 = INFINITY;
+                                for (int k = 0; k < PGM_KF8; ++k) { ni[v].fd[k] = 0; ni[v].fc[k] = INFINITY; }
+                                ni[v].flags = PGM_NF_GENERIC | (1u << 8) | (ni[v].flags & PGM_NF_KILL);
+                            }
+                    }
+                }
                 o.M = A.put(model[i]->M, sizeof(double) * J.dim * J.dim);
                 o.pi = A.put(model[i]->pi, sizeof(double) * J.dim);
                 if (A.overflow) bad.store((int)i);
@@ -460,7 +491,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // free it takes, among the items that are READY by then, the one with the longest remaining path (the time until its
     // job is complete: the lags still ahead, one full sweep, the traceback).  Within a job the items keep ascending
     // order, as the kernel requires; taking only ready items keeps workers from idling in front of a predecessor band.
-    // Step times (us, one wavefront per band): ~0.2 for a chain-only band, ~0.35 with the near-predecessor window.
+    // Step times (us, measured with the whole batch resident): ~0.45 for a chain-only band (the leaf level is bound by the
+    // HBM write bandwidth), ~0.65 with the near window and the far history in the sweeping wavefront, ~0.4 with helpers.
     std::vector<PgmItem> items;
     uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
     // persistent workers: 2 workgroups of 4 wavefronts per CU (each owns half of the CU's LDS for its sweeps' histories)
@@ -471,12 +503,12 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         std::vector<std::vector<Item>> per_job(njobs);
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };   // experiments only
-        const double tau_x = envd("PGM_SIM_TAU_X", 0.35), tau_c = envd("PGM_SIM_TAU_C", 0.2), eager = envd("PGM_SIM_EAGER", 0.7);
+        const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.4), eager = envd("PGM_SIM_EAGER", 0.7);
         size_t total = 0;
         double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {
             const PgmJob &J = b->jobs[i];
-            const double tau = J.has_extras ? tau_x : tau_c;     // us per step
+            const double tau = J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c);     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             const uint32_t group = J.nslots;                     // bands per item, one per wavefront of the worker
             for (uint32_t band = 0; band < J.nb; band += group) {

@@ -10,25 +10,37 @@
 #define PGM_VL 16          /* virtual lanes: the last 16 rows of the previous band, kept in the LDS history of the band below */
 #define PGM_BLOCK 8        /* steps between two synchronisation points of a band */
 #define PGM_NRING 128      /* columns of graph 2 whose predecessor summary is kept in LDS per sweeping wavefront */
-#define PGM_KF 4           /* "far" predecessors per node served from the LDS history */
+#define PGM_KF 4           /* "far" predecessors per node served from the LDS history by a self-contained sweep (MODE 1) */
+#define PGM_KF8 8          /* ... by the far helper of a MODE 2 sweep */
 #define PGM_DCAP 28        /* largest predecessor distance served on chip (farther: generic path through the cell storage) */
 #define PGM_POOL 81408     /* LDS bytes of a fill worker (two workers per CU: 2 x (81408 + 512) = 160 KiB) */
+/* extra LDS of a MODE 2 sweep (PgmJob::mode2: three helper wavefronts evaluate all but the chain terms), at PgmJob::aux_off: */
+#define PGM_AUX_RES 0      /* float res[3 groups][4][3][64]: partial maxima {M, X, Y} per lane of the steps t & 3, per helper group */
+#define PGM_AUX_SBLK 9216  /* float sblk[8][64]: emission scores of the far helper's current block (entry lanes read their owner's) */
+#define PGM_AUX_EL 11264   /* uint2 elist[512]: far row entries of the band {owner lane | distance << 8, cost} */
+#define PGM_AUX_CNT 15360  /* int: number of entries */
+#define PGM_AUX_BYTES 15376
 
-// Per-node predecessor summary prepared by the host from the CSR (48 bytes = 3 float4).
-//   q0 = {cc, c2, c3, flags}   q1 = {fd0..fd3}   q2 = {fc0..fc3}
+// Per-node predecessor summary prepared by the host from the CSR (80 bytes = 5 float4).
+//   q0 = {cc, c2, c3, flags}   q1 = {fd0..fd3}   q2 = {fd4..fd7}   q3 = {fc0..fc3}   q4 = {fc4..fc7}
 //   cc, c2, c3  cost of the edge from node-1 / node-2 / node-3 ("near" predecessors, served from registers of the
 //               sweeping wavefront), +inf if absent: an absent edge then contributes -inf to every max without masking
-//   flags  bits 0-2: number of "far" predecessors (any other edge; <= PGM_KF), served from the on-chip history
+//   flags  bits 0-3: number of "far" predecessors (any other edge), served from the on-chip history: at most PGM_KF8 in a
+//                    MODE 2 job (far helper), at most PGM_KF otherwise
 //          bits 8-15: largest distance among all on-chip predecessors of the node (>= 1)
-//          bit 3   : generic — more than PGM_KF far edges or a distance > PGM_DCAP: every non-chain predecessor of this
+//          bit 4   : generic — more far edges than that or a distance > PGM_DCAP: every non-chain predecessor of this
 //                    node is read from the cell storage through the CSR lists (xp/xc/xv); then c2 = c3 = +inf, no far entries
-//          bit 4   : kill — interior node without any predecessor
+//          bit 5   : kill — interior node without any predecessor
 //   fd_k   (node - predecessor) of far edge k, 0 if absent;   fc_k its cost, +inf if absent
+// The column ring of a sweep keeps {q0, q1, q3} (MODE 0 / 1: 3 float4 per column) or all five (MODE 2).
+#define PGM_NF_COUNT 15u
+#define PGM_NF_GENERIC 16u
+#define PGM_NF_KILL 32u
 struct PgmNode2 {
     float cc, c2, c3;
     uint32_t flags;
-    uint32_t fd[PGM_KF];
-    float fc[PGM_KF];
+    uint32_t fd[PGM_KF8];
+    float fc[PGM_KF8];
 };
 
 // One alignGraphs job, resident in HBM.  All pointers are device pointers.
@@ -62,6 +74,9 @@ struct PgmJob {
     uint32_t maxn;         // max(n1,n2)
     uint32_t has_extras;   // some node of either graph has a predecessor other than its chain neighbour
     uint32_t has_far;      // some node has a predecessor served from the LDS history (the sweeps then record W, Y, X there)
+    uint32_t mode2;        // one band per worker: the other three wavefronts evaluate every term but the two chain terms (nslots = 1)
+    uint32_t far_slack;    // min(4, smallest far distance): the far helper may evaluate step t once step t - far_slack is recorded
+    uint32_t aux_off;      // offset of the helper area (PGM_AUX_*) inside a sweep's LDS slot
     uint32_t hD, hDX;      // depth (steps, power of two) of the W / Y history and of the X history of a sweeping wavefront
     uint32_t slot_bytes;   // LDS bytes one sweeping wavefront needs for this job (history + column rings)
     uint32_t nslots;       // bands of this job one worker sweeps at a time = min(4, PGM_POOL / slot_bytes)

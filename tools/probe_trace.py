@@ -13,6 +13,9 @@ dump = os.path.join(tmp, "jobs.bin")
 subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree"), "--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
 jobs = J.load_jobs(dump)
 os.environ["PGM_FILL_TRACE"] = trace
+for kv in os.environ.get("PROBE_ENV", "").split(","):   # experiment knobs that must not reach the product run above
+    if "=" in kv:
+        os.environ[kv.split("=")[0]] = kv.split("=")[1]
 ctx = pg.Context(0)
 b = J.Batch(ctx, jobs)
 b.run(); b.fetch(); b.run(); b.fetch()
@@ -66,3 +69,5 @@ for nm, mm in (("chain-only items", ext[items[:, 0]] == 0), ("merged items", ext
 for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
     print("root job: bands %d, first start %.0f, last band end %.0f, tb end %.0f" % (m.sum(), start[m].min(), bend[m].max(), tend[m].max()))
+    for i in np.where(m)[0][np.argsort(items[m][:, 1])]:
+        print("   band %2d: start %6.0f  wait %6.0f  end %6.0f  (running %.0f us = %.3f us/step; of which waiting for the helper %.0f us)" % (items[i, 1], start[i], wait_us[i], bend[i], bend[i] - start[i] - wait_us[i], (bend[i] - start[i] - wait_us[i]) / steps[i], raw[i, 4] / 100.0 if tend[i] == 0 else -1))
