@@ -4,14 +4,24 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset, N > 1) starts that launcher itself, before anything
+touches a GPU, and passes its output through.
+
 Workload (config.workload): the 255 graph-vs-graph alignGraphs jobs of one progressive pass over the synthetic
 256 x 1000 aa family (tests/gen.py seed 3, guide tree tests/golden/c3.tree, --mldist), 2.71e8 DP cells, exactly the
 jobs the product driver issues (captured with `pgmsa --dump_jobs` on this GPU during untimed set-up).
 One "step" = one pass of the hot path over that batch with the inputs resident in HBM: prep (float casts,
 T = M^T g2) + emission scores + the fill kernel (DP fill of every band and, after a job's last band, its traceback),
 then the result/mapping copy back to the host.
-Multi-GPU: one process per GPU, every rank runs the same workload on its own device (independent jobs, no collective
-on the data path; weak scaling); torch.distributed is used only for the barrier and the max-over-ranks clock.
+
+Multi-GPU: one process per GPU, no collective on the data path (torch.distributed only provides the barrier, the
+max-over-ranks clock and the rendezvous store that serves the work queue's ticket counter).
+  value              every rank runs the headline batch on its own device (weak scaling of independent batches)
+  all_pairs_nw*      STRONG scaling of the all-pairs stage (DistanceFactoryAlign): the alignPair jobs of the family, cut into
+                     tiles (longest first) that the ranks pull from one atomic ticket counter (prographmsa_amd/farm.py, the
+                     process-per-GPU twin of the product's farm in host/distance.cpp); 256 x 1000 and 1024 x 600 families
+  progressive_strong STRONG scaling of the progressive pass: the 255 captured jobs dealt to the ranks (longest first);
+                     bounded by the root job's critical path, reported as measured
 """
 import argparse
 import json
@@ -26,7 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -34,20 +44,75 @@ def main():
     ap.add_argument("--nseq", type=int, default=256, help="debug: smaller family (changes the workload; not the headline)")
     ap.add_argument("--len", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-records (configs 4 / 5, 1024 x 600 all-pairs, strong scaling)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no compute: only the launch / rendezvous / work-queue / aggregation plumbing (gloo), for CPU rehearsals")
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run (before any GPU call)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     import torch
     import torch.distributed as dist
+    from prographmsa_amd import farm
+
+    if args.dry_run:
+        # plumbing rehearsal: rendezvous, ticket queue, barrier, max-over-ranks clock, sum of the units; nothing is computed
+        if world > 1:
+            dist.init_process_group("gloo")
+        q = farm.TicketQueue("dry_tiles", world)
+        ntiles, mine = 64, []
+        while True:
+            t = q.next()
+            if t >= ntiles:
+                break
+            mine.append(t)
+            time.sleep(0.001)
+        units = torch.tensor([float(len(mine))], dtype=torch.float64)
+        clock = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(units, op=dist.ReduceOp.SUM)
+            dist.all_reduce(clock, op=dist.ReduceOp.MAX)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+        else:
+            gathered = [mine]
+        if rank == 0:
+            once = sorted(t for g in gathered for t in g) == list(range(ntiles))
+            print(json.dumps({"metric": "DP cell-updates/sec (GCUPS) + wall-clock on 256 seqs × 1000 aa, WAG", "value": None, "unit": "GCUPS",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True, "tiles": ntiles, "tiles_pulled": int(units.item()),
+                              "every_tile_exactly_once": once, "max_clock": clock.item()}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import ctypes as C
+    import hashlib
     import numpy as np
     import gen
     import prographmsa_amd as pg
@@ -55,55 +120,79 @@ def main():
 
     ctx = pg.Context(local_rank)
     devname, cus = ctx.device_info()
-
-    # ---- untimed set-up: produce the jobs with the product driver on this GPU --------------------
-    tmp = tempfile.mkdtemp(prefix="pgm_bench_r%d_" % rank)
-    fa = os.path.join(tmp, "fam.fa")
-    headline = (args.nseq == 256 and args.len == 1000)
-    with open(fa, "w") as f:
-        f.write(gen.fasta(gen.gen(args.nseq, args.len, 3)))
-    env = dict(os.environ, PGM_DEVICE=str(local_rank))
-    dump = os.path.join(tmp, "jobs.bin")
-    if headline:
-        tree_args = ["-t", os.path.join(ROOT, "tests", "golden", "c3.tree")]
-    else:   # debug sizes: NW guide tree from the GPU all-pairs stage
-        tr = subprocess.run([pg.PGMSA_PATH, "-a", "-m", "-T", "-i", "0", fa], capture_output=True, text=True, env=env, check=True).stdout
-        with open(os.path.join(tmp, "t.tree"), "w") as f:
-            f.write(tr)
-        tree_args = ["-t", os.path.join(tmp, "t.tree")]
-    t0 = time.time()
-    r = subprocess.run([pg.PGMSA_PATH, "--fasta", "-m"] + tree_args + ["--dump_jobs", dump, "--stats", "-o", os.path.join(tmp, "out.fa"), fa],
-                       capture_output=True, text=True, env=env)
-    if r.returncode != 0:
-        raise SystemExit("pgmsa failed: " + r.stderr)
-    e2e_wall = time.time() - t0
-    stats = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
-    # the reference's default flow from sequences alone (`--fasta -a`: all-pairs guide tree, two rounds of progressive
-    # alignment + guide-tree re-estimation, final alignment), rank 0 only; the FASTA's md5 is checked against the fixture of
-    # the reference binary's output for the headline family
-    default_flow = None
-    if rank == 0:
-        t0 = time.time()
-        r2 = subprocess.run([pg.PGMSA_PATH, "--fasta", "-a", "--stats", fa], capture_output=True, text=True, env=env)
-        dt2 = time.time() - t0
-        if r2.returncode == 0:
-            import hashlib
-            st2 = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
-            default_flow = {"cmd": "pgmsa --fasta -a", "wall_s": round(dt2, 3), "tree_s": st2["tree_s"], "progressive_s": st2["progressive_s"],
-                            "align_cells": st2["align_cells"], "nw_cells": st2["nw_cells"]}
-            if headline:
-                want = json.load(open(os.path.join(ROOT, "tests", "golden", "md5.json"))).get("c3.a_iter.out.fa")
-                default_flow["fasta_identical_to_reference"] = (hashlib.md5(r2.stdout.encode()).hexdigest() == want)
-                default_flow["reference_wall_s"] = 919   # bin/ProGraphMSA_64 --fasta -a, one core of the build container
-    jobs = J.load_jobs(dump)
-    os.remove(dump)
-    batch = J.Batch(ctx, jobs)
-    cells = batch.cells
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    md5s = json.load(open(os.path.join(ROOT, "tests", "golden", "md5.json")))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def sum_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(t.item())
+        return x
+
+    # ---- untimed set-up: produce the jobs with the product driver on this GPU --------------------
+    tmp = tempfile.mkdtemp(prefix="pgm_bench_r%d_" % rank)
+    env = dict(os.environ, PGM_DEVICE=str(local_rank))
+
+    def capture(fasta_text, flags, name):
+        """Runs pgmsa on a family (untimed), returns (jobs, stats, md5 of the FASTA it printed)."""
+        fa = os.path.join(tmp, name + ".fa")
+        with open(fa, "w") as f:
+            f.write(fasta_text)
+        dump = os.path.join(tmp, name + ".jobs")
+        t0 = time.time()
+        r = subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "--stats", fa], capture_output=True, text=True, env=env)
+        if r.returncode != 0:
+            raise SystemExit("pgmsa failed: " + r.stderr)
+        wall = time.time() - t0
+        st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+        st["wall_s"] = round(wall, 3)
+        js = J.load_jobs(dump)
+        os.remove(dump)
+        return js, st, hashlib.md5(r.stdout.encode()).hexdigest()
+
+    headline = (args.nseq == 256 and args.len == 1000)
+    fam = gen.gen(args.nseq, args.len, 3)
+    if headline:
+        tree_args = ["-t", os.path.join(ROOT, "tests", "golden", "c3.tree")]
+    else:   # debug sizes: NW guide tree from the GPU all-pairs stage
+        fa0 = os.path.join(tmp, "t.fa")
+        open(fa0, "w").write(gen.fasta(fam))
+        tr = subprocess.run([pg.PGMSA_PATH, "-a", "-m", "-T", "-i", "0", fa0], capture_output=True, text=True, env=env, check=True).stdout
+        with open(os.path.join(tmp, "t.tree"), "w") as f:
+            f.write(tr)
+        tree_args = ["-t", os.path.join(tmp, "t.tree")]
+    jobs, stats, out_md5 = capture(gen.fasta(fam), ["--fasta", "-m"] + tree_args, "c3")
+    # the reference's default flow from sequences alone (`--fasta -a`: all-pairs guide tree, two rounds of progressive
+    # alignment + guide-tree re-estimation, final alignment), rank 0 only; the FASTA's md5 is checked against the fixture of
+    # the reference binary's output for the headline family
+    default_flow = None
+    if rank == 0:
+        fa0 = os.path.join(tmp, "c3.fa")
+        t0 = time.time()
+        r2 = subprocess.run([pg.PGMSA_PATH, "--fasta", "-a", "--stats", fa0], capture_output=True, text=True, env=env)
+        dt2 = time.time() - t0
+        if r2.returncode == 0:
+            st2 = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+            default_flow = {"cmd": "pgmsa --fasta -a", "wall_s": round(dt2, 3), "tree_s": st2["tree_s"], "progressive_s": st2["progressive_s"],
+                            "align_cells": st2["align_cells"], "nw_cells": st2["nw_cells"]}
+            if headline:
+                default_flow["fasta_identical_to_reference"] = (hashlib.md5(r2.stdout.encode()).hexdigest() == md5s.get("c3.a_iter.out.fa"))
+                default_flow["reference_wall_s"] = 919   # bin/ProGraphMSA_64 --fasta -a, one core of the build container
+    batch = J.Batch(ctx, jobs)
+    cells = batch.cells
 
     for _ in range(args.warmup):
         batch.run()
@@ -117,72 +206,102 @@ def main():
         batch.run()          # pgm_align_batch_run: prep + emission + fill/traceback kernels
         batch.fetch_raw()    # pgm_align_batch_fetch: wait, D2H of scores and mappings into the caller's buffers
     barrier()
-    dt = time.perf_counter() - t0
-    total_cells = float(cells) * args.steps
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([total_cells], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        dt, total_cells = float(t.item()), float(c.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
+    total_cells = sum_over_ranks(float(cells) * args.steps)
 
     # ---- roofline of the dominant kernel (pgm_fill_kernel: DP fill + tracebacks), HIP events on the library's stream ----
-    reps = sorted(batch.time(1) for _ in range(7))          # per-stage device times, median of 7 single runs
-    ms_prep, ms_emis = sorted(r[0] for r in reps)[3], sorted(r[1] for r in reps)[3]
-    ms_fill = sorted(r[2] for r in reps)[3]
+    reps = [batch.time(1) for _ in range(7)]          # per-stage device times, median of 7 single runs
+    ms_prep, ms_emis, ms_fill = (sorted(r[k] for r in reps)[3] for k in range(3))
     alg_bytes = 16.0 * cells            # one float4 {M,X,W,Y} store per cell; S is materialised by the emission
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_v22_pmc.json")
+    traffic, pmc_name = None, "profiles/r2_pmc.json"
+    pmc_path = os.path.join(ROOT, pmc_name)
     if headline and os.path.exists(pmc_path):
-        pmc_all = json.load(open(pmc_path))
-        pmc = next((v for k, v in pmc_all.items() if k.startswith("pgm_fill_kernel")), {})
+        pmc = next((v for k, v in json.load(open(pmc_path)).items() if k.startswith("pgm_fill_kernel")), {})
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                "traffic_source": "profiles/r1_v22_pmc.json (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
+                "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
                 "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4)},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
 
-    # ---- all-pairs stage (DistanceFactoryAlign, `-a`): the 32 640 alignPair jobs of the same family, sharded over the
-    # ranks (strong scaling of this stage: no collective, rank 0 would gather counts/gaps) --------------------------------
-    import ctypes as C
-    from prographmsa_amd import workqueue as wq
-    seqs_aa = gen.gen(args.nseq, args.len, 3)
-    order = "ACDEFGHIKLMNPQRSTVWY"
-    enc = [np.array([order.index(c) for c in s[1:] if True] if s.startswith("M") else [order.index(c) for c in s], np.int8) for s in seqs_aa]
-    lens = [len(e) for e in enc]
-    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
-    syms = np.concatenate(enc).astype(np.int8)
-    pairs = wq.all_pairs(len(enc))
-    mine = wq.shard_pairs(lens, rank, world)
-    pi = np.array([pairs[p][0] for p in mine], np.uint32)
-    pj = np.array([pairs[p][1] for p in mine], np.uint32)
-    score = np.loadtxt(os.path.join(ROOT, "prographmsa_amd", "host", "data", "nw_aa.imat"), skiprows=1, dtype=np.int32).reshape(-1)
-    counts = np.zeros(len(mine) * 400, np.int32)
-    gaps = np.zeros(len(mine), np.uint32)
-    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    nw_cells = float(sum(lens[pairs[p][0]] * lens[pairs[p][1]] for p in mine))
+    # ---- strong scaling of the progressive pass: the same jobs dealt to the ranks (longest first), one pass ---------------
+    prog_strong = None
+    if world > 1 and not args.no_extra:
+        shards = farm.lpt_shards([j.cells for j in jobs], world)
+        mine = [jobs[i] for i in shards[rank]]
+        sb = J.Batch(ctx, mine)
+        sb.run(); sb.fetch_raw()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sb.run()
+            sb.fetch_raw()
+        barrier()
+        sdt = max_over_ranks(time.perf_counter() - t0)
+        prog_strong = {"jobs_per_rank": [len(s) for s in shards], "ms_per_pass": round(sdt / args.steps * 1e3, 4),
+                       "gcups": round(cells * args.steps / sdt / 1e9, 3), "scaling": "strong",
+                       "note": "one pass = all 255 jobs across the ranks; the root job (1.7 % of the cells) is a single critical path"}
+        sb.close()
 
-    def nw_call():
-        pg.check(pg.lib.pgm_nw_pairs_batch(ctx.handle, 20, P(score, C.c_int32), -10, -2, len(enc), P(syms, C.c_int8), P(offs, C.c_uint32),
-                                           len(mine), P(pi, C.c_uint32), P(pj, C.c_uint32), P(counts, C.c_int32), P(gaps, C.c_uint32)))
-    nw_call()
-    barrier()
-    t0 = time.perf_counter()
-    nw_call()
-    barrier()
-    nw_dt = time.perf_counter() - t0
-    nw_kernel_ms = float(pg.lib.pgm_nw_last_kernel_ms(ctx.handle))
-    nw_total = nw_cells
-    if world > 1:
-        t = torch.tensor([nw_dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([nw_cells], dtype=torch.float64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        nw_dt, nw_total = float(t.item()), float(c.item())
+    # ---- all-pairs stage (DistanceFactoryAlign, `-a`): alignPair tiles pulled by the ranks from one ticket counter --------
+    score = np.loadtxt(os.path.join(ROOT, "prographmsa_amd", "host", "data", "nw_aa.imat"), skiprows=1, dtype=np.int32).reshape(-1)
+    order = "ACDEFGHIKLMNPQRSTVWY"
+
+    def all_pairs_stage(seqs_aa, tag):
+        enc = [np.array([order.index(c) for c in (s[1:] if s.startswith("M") else s)], np.int8) for s in seqs_aa]
+        lens = [len(e) for e in enc]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        syms = np.concatenate(enc).astype(np.int8)
+        pairs = farm.sorted_pairs(lens)
+        npairs = len(pairs)
+        pi_all = np.array([p[0] for p in pairs], np.uint32)
+        pj_all = np.array([p[1] for p in pairs], np.uint32)
+        tile = farm.tile_size(npairs, world, os.environ.get("PGM_NW_TILE"))
+        ntiles = (npairs + tile - 1) // tile
+        counts = np.zeros(tile * 400, np.int32)
+        gaps = np.zeros(tile, np.uint32)
+        kernel_ms = [0.0]
+
+        def run(qname):
+            q = farm.TicketQueue(qname, world)
+            done_cells, done_tiles = 0.0, 0
+            kernel_ms[0] = 0.0
+            while True:
+                t = q.next()
+                if t >= ntiles:
+                    break
+                p0, cnt = t * tile, min(tile, npairs - t * tile)
+                pg.check(pg.lib.pgm_nw_pairs_batch(ctx.handle, 20, P(score, C.c_int32), -10, -2, len(enc), P(syms, C.c_int8), P(offs, C.c_uint32),
+                                                   cnt, P(pi_all[p0:], C.c_uint32), P(pj_all[p0:], C.c_uint32), P(counts, C.c_int32), P(gaps, C.c_uint32)))
+                kernel_ms[0] += float(pg.lib.pgm_nw_last_kernel_ms(ctx.handle))
+                done_cells += float(sum(lens[a] * lens[b] for a, b in pairs[p0:p0 + cnt]))
+                done_tiles += 1
+            return done_cells, done_tiles
+        run(tag + "_warm")
+        barrier()
+        t0 = time.perf_counter()
+        my_cells, my_tiles = run(tag + "_timed")
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        tot = sum_over_ranks(my_cells)
+        tiles_per_rank = [my_tiles]
+        if world > 1:
+            tiles_per_rank = [None] * world
+            dist.all_gather_object(tiles_per_rank, my_tiles)
+        return {"pairs_total": npairs, "cells_total": tot, "tile_pairs": tile, "tiles": ntiles, "tiles_per_rank": tiles_per_rank,
+                "wall_s": round(wall, 4), "gcups_wall": round(tot / wall / 1e9, 2), "rank0_kernel_ms": round(kernel_ms[0], 3),
+                "rank0_kernel_gcups": round(my_cells / max(kernel_ms[0], 1e-9) / 1e6, 2), "scaling": "strong",
+                "note": "tiles of alignPair jobs (longest first) pulled by the ranks from one ticket counter; whole pgm_nw_pairs_batch calls "
+                        "incl. H2D of the sequences and D2H of the 400-int count matrices; 2 direction bits/cell stored "
+                        "(reference formulation: 12 B/cell)"}
+    nw = all_pairs_stage(fam, "nw_c3")
+    nw_big = None
+    if headline and not args.no_extra:
+        nw_big = all_pairs_stage(gen.gen(1024, 600, 6), "nw_c5")
+        nw_big["family"] = "1024 x 600 aa (BASELINE config 5 inputs): 523 776 pairs"
 
     # ---- context-specific leaf profiles (CSProfile::createProfile) at the scale of BASELINE config 5: a synthetic library
     # of K = 4000 context profiles (13 columns), the leaves of a 1024 x 600 aa family sharded over the ranks --------------
@@ -198,7 +317,7 @@ def main():
         lpf = np.ascontiguousarray(lp, np.float64).reshape(-1)
         cf = np.ascontiguousarray(p[:, ncols // 2, :], np.float64).reshape(-1)
         prf = np.log(rng.dirichlet(np.ones(K)))
-        lo, hi = wq.shard_range(nleaf, rank, world)
+        lo, hi = farm.shard_range(nleaf, rank, world)
         nl = hi - lo
         syms_cs = rng.integers(0, 20, nl * L).astype(np.int8)
         offs_cs = (np.arange(nl + 1) * L).astype(np.uint32)
@@ -217,17 +336,44 @@ def main():
         t0 = time.perf_counter()
         cs_call()
         barrier()
-        cs_dt = time.perf_counter() - t0
+        cs_dt = max_over_ranks(time.perf_counter() - t0)
         cs_ms = float(pg.lib.pgm_csprofile_last_kernel_ms(ctx.handle))
-        if world > 1:
-            t = torch.tensor([cs_dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cs_dt = float(t.item())
         flop = 34.0 * K * L * nleaf   # ~K*L*34 flop per sequence (fp64)
         cs = {"library": "synthetic K=%d x %d columns" % (K, ncols), "sequences_total": nleaf, "length": L, "wall_s": round(cs_dt, 4),
               "rank0_kernel_ms": round(cs_ms, 3), "gflops_wall": round(flop / cs_dt / 1e9, 1), "scaling": "strong",
               "note": "whole pgm_csprofile_create_batch call incl. H2D of the residues and D2H of the 20 x (L+2) fp64 profiles; "
                       "reference config 5 spends ~450 s of 510 s in createProfile"}
+
+    # ---- BASELINE configs 4 and 5 at full size (rank 0, N = 1): one progressive pass on the committed guide trees ----------
+    configs = None
+    if headline and rank == 0 and world == 1 and not args.no_extra:
+        configs = {}
+        lib_path = os.path.join(tmp, "K4000syn.lib")
+        with open(lib_path, "w") as f:
+            f.write(gen.genlib(4000, 11))
+        gold = os.path.join(ROOT, "tests", "golden")
+        for name, text, flags, ref_md5, ref_s in (
+                ("config4_128x1000_codons", gen.fasta(gen.gen_codon(128, 1000, 4)), ["--codon", "--fasta", "-t", os.path.join(gold, "c4.tree")], "c4.out.fa", 10),
+                ("config5_1024x600_aa", gen.fasta(gen.gen(1024, 600, 6)), ["--fasta", "-t", os.path.join(gold, "c5.tree")], "c5.out.fa", 21),
+                ("config5_1024x600_aa_K4000", gen.fasta(gen.gen(1024, 600, 6)),
+                 ["--fasta", "-t", os.path.join(gold, "c5.tree"), "--cs_profile", lib_path], "c5.cs.out.fa", 170)):
+            js, st, md5 = capture(text, flags, name)
+            b2 = J.Batch(ctx, js)
+            b2.run(); b2.fetch_raw()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                b2.run()
+                b2.fetch_raw()
+            d2 = (time.perf_counter() - t0) / 5
+            tm = sorted(b2.time(1) for _ in range(3))[1]
+            configs[name] = {"jobs": len(js), "cells": b2.cells, "dim": js[0].g1.dim, "ms_per_pass": round(d2 * 1e3, 3),
+                             "gcups": round(b2.cells / d2 / 1e9, 3), "ms": {"prep": round(tm[0], 3), "emission": round(tm[1], 3), "fill_and_traceback": round(tm[2], 3)},
+                             "fill_frac_of_hbm_roofline": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 4),
+                             "pgmsa": {"wall_s": st["wall_s"], "progressive_s": st["progressive_s"], "align_call_s": st["align_s"]},
+                             "fasta_identical_to_reference": md5 == md5s.get(ref_md5), "reference_one_pass_s": ref_s,
+                             "note": "jobs of one progressive pass captured from the product driver, inputs resident in HBM; "
+                                     "reference time: bin/ProGraphMSA_64 on one core of the build container"}
+            b2.close()
 
     out = None
     if rank == 0:
@@ -241,14 +387,14 @@ def main():
                                    "(%.3e DP cells) per GPU, inputs resident in HBM" % (args.nseq, args.len, len(jobs), cells),
                        "headline": headline, "device": devname, "cus": cus, "jobs": len(jobs), "cells_per_step": cells},
             "roofline": roofline,
-            "all_pairs_nw": {"pairs_total": len(pairs), "cells_total": nw_total, "wall_s": round(nw_dt, 4),
-                             "gcups_wall": round(nw_total / nw_dt / 1e9, 2), "rank0_kernel_ms": round(nw_kernel_ms, 3),
-                             "rank0_kernel_gcups": round(nw_cells / (nw_kernel_ms * 1e-3) / 1e9, 2), "scaling": "strong",
-                             "note": "whole pgm_nw_pairs_batch call incl. H2D of sequences and D2H of the 400-int count matrices; "
-                                     "2 direction bits/cell stored (reference formulation: 12 B/cell)"},
+            "all_pairs_nw": nw,
+            "all_pairs_nw_1024x600": nw_big,
+            "progressive_strong": prog_strong,
             "csprofile": cs,
-            "end_to_end": {"pgmsa_wall_s": round(e2e_wall, 3), "progressive_s": stats["progressive_s"],
-                           "align_call_s": stats["align_s"], "note": "untimed set-up run of the product driver incl. host merges, H2D/D2H and hipMalloc",
+            "configs": configs,
+            "end_to_end": {"pgmsa_wall_s": stats["wall_s"], "progressive_s": stats["progressive_s"], "align_call_s": stats["align_s"],
+                           "fasta_identical_to_reference": (out_md5 == md5s.get("c3.out.fa")) if headline else None,
+                           "note": "untimed set-up run of the product driver incl. host merges, H2D/D2H and hipMalloc",
                            "default_flow": default_flow},
         }
         if world == 1 and not args.no_cpu_baseline:

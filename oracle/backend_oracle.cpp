@@ -3,6 +3,9 @@
 // the reference binary's FASTA output (tests/test_oracle_golden.py).  Never linked into the product.
 #include "../prographmsa_amd/host/pgm_host.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 extern "C" {
 int pgmo_align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                             const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out);
@@ -22,9 +25,12 @@ struct OracleBackend : Backend {
                             const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) override {
         pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out);
     }
+    // PGM_FARM_WORKERS=k: the all-pairs farm of the host scaffolding runs with k host threads over this (stateless,
+    // re-entrant) CPU oracle: the 1-vs-k-workers identity test of tests/test_cpu_host.py
+    int workers() const override { const char *e = getenv("PGM_FARM_WORKERS"); return e ? std::max(1, atoi(e)) : 1; }
     void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
                         const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
-                        uint32_t *gaps) override {
+                        uint32_t *gaps, int) override {
         if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps) != PGM_OK)
             error("error while backtracking");
     }

@@ -1037,10 +1037,8 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             const uint32_t rslot = (x & (uint32_t)(NR - 1)) * (uint32_t)RS;
             const float4 cn = cn_n;
             const float iW1 = inW1, iY1 = inY1, iW2 = inW2, iY2 = inY2, iW3 = inW3, iY3 = inY3;
-            float hM = PGM_NEG_INF, hX_ = PGM_NEG_INF, hY_ = PGM_NEG_INF;
             if (HELPED && !(dbg_flags & 2u)) {
-                // partial maxima of the helper wavefronts for this step (they run ahead: normally no wait).  The reads are issued
-                // here, together with the other LDS operands, and consumed after the chain terms.
+                // the helper wavefronts run ahead: normally their terms of this step are already published (no LDS access here)
                 const int want = (int)t + 1;
                 if (seenA < want || seenB < want || seenC < want) {
                     uint32_t spins = 0;
@@ -1058,13 +1056,6 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                     if (wait_acc) wait_acc[1] += __builtin_amdgcn_s_memrealtime() - h0;
                 }
                 asm volatile("" ::: "memory");
-                const uint32_t ro = (t & 3u) * 192u + (uint32_t)lane;
-                if (!(dbg_flags & 32u)) { hM = resA[ro]; hX_ = resA[ro + 64]; hY_ = resA[ro + 128]; }
-                if (use_far) {
-                    hM = fmaxf(hM, fmaxf(resB[ro], resC[ro]));
-                    hX_ = fmaxf(hX_, resB[ro + 64]);
-                    hY_ = fmaxf(hY_, resC[ro + 128]);
-                }
             }
             {   // operands of step t + 1 (their virtual-lane entries and column summaries were staged at least a block ago)
                 cn_n = ring3[((x + 1u) & (uint32_t)(NR - 1)) * (uint32_t)RS];
@@ -1072,6 +1063,13 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 inW1 = hW[tm0 + VL - 1]; inY1 = hY[tm0 + VL - 1];
                 if (EXTRAS) { inW2 = hW[tm1 + VL - 2]; inY2 = hY[tm1 + VL - 2]; }
                 if (NEAR) { inW3 = hW[tm2 + VL - 3]; inY3 = hY[tm2 + VL - 3]; }
+            }
+            // partial maxima of the helpers for this step: issued with the other LDS operands, merged after the chain terms
+            float rAM = PGM_NEG_INF, rAX = PGM_NEG_INF, rAY = PGM_NEG_INF, rBM = PGM_NEG_INF, rBX = PGM_NEG_INF, rCM = PGM_NEG_INF, rCY = PGM_NEG_INF;
+            if (HELPED && !(dbg_flags & 2u)) {
+                const uint32_t ro = (t & 3u) * 192u + (uint32_t)lane;
+                if (!(dbg_flags & 32u)) { rAM = resA[ro]; rAX = resA[ro + 64]; rAY = resA[ro + 128]; }
+                if (use_far) { rBM = resB[ro]; rBX = resB[ro + 64]; rCM = resC[ro]; rCY = resC[ro + 128]; }
             }
             const float ccx = cn.x, c2x = EXTRAS ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
             const uint32_t fx = __float_as_uint(cn.w);
@@ -1103,10 +1101,10 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 Xv = fmaxf(Xv, xterm(ox[sm2], ow[sm2], c2x));
                 Yv = fmaxf(Yv, yterm(u2Y, u2W[s0], c2y));
             }
-            if (HELPED && !(dbg_flags & 2u)) {
-                Mv = fmaxf(Mv, hM);
-                Xv = fmaxf(Xv, hX_);
-                Yv = fmaxf(Yv, hY_);
+            if (HELPED) {
+                Mv = fmaxf(fmaxf(Mv, rAM), fmaxf(rBM, rCM));
+                Xv = fmaxf(Xv, fmaxf(rAX, rBX));
+                Yv = fmaxf(Yv, fmaxf(rAY, rCY));
             }
             if (NEAR) {
                 Mv = fmaxf(Mv, fmaxf(mterm(u1W[sm2], ccy, c2x), mterm(u1W[sm3], ccy, c3x)));

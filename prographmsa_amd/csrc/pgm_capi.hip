@@ -39,6 +39,14 @@ struct pgm_ctx {
     size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0, 0};
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0;
+    // grow-only scratch buffers of the all-pairs / context-profile calls (slot = position in the call's buffer list): a
+    // guide-tree stage issues many calls (one per pair tile), hipMalloc / hipFree of up to 2 GB per call would dominate them
+    enum { SC_DEV = 24, SC_HOST = 4 };
+    void *sc_dev[SC_DEV] = {};
+    size_t sc_dev_bytes[SC_DEV] = {};
+    void *sc_host[SC_HOST] = {};      // pinned
+    size_t sc_host_bytes[SC_HOST] = {};
+    hipEvent_t sc_ev[2] = {nullptr, nullptr};
     // context-profile library resident in HBM
     uint32_t csK = 0, csC = 0;
     double *cs_lprofiles = nullptr, *cs_centre = nullptr, *cs_priors = nullptr;
@@ -125,6 +133,9 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_lprofiles) (void)hipFree(ctx->cs_lprofiles);
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
+    for (int k = 0; k < pgm_ctx::SC_DEV; ++k) if (ctx->sc_dev[k]) (void)hipFree(ctx->sc_dev[k]);
+    for (int k = 0; k < pgm_ctx::SC_HOST; ++k) if (ctx->sc_host[k]) (void)hipHostFree(ctx->sc_host[k]);
+    for (int k = 0; k < 2; ++k) if (ctx->sc_ev[k]) (void)hipEventDestroy(ctx->sc_ev[k]);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
         if (ctx->cache_ptr[k]) { if ((k == pgm_ctx::C_HOST || k == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[k]); else (void)hipFree(ctx->cache_ptr[k]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -253,6 +264,39 @@ static void cache_give(pgm_ctx *ctx, int slot, void *p, size_t bytes) {
     } else {
         if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(p); else (void)hipFree(p);
     }
+}
+
+// scratch buffer `slot` of the context with room for `bytes` (device memory, or pinned host memory)
+static hipError_t scratch_dev(pgm_ctx *ctx, int slot, size_t bytes, void **out) {
+    bytes = std::max<size_t>(bytes, 16);
+    if (ctx->sc_dev_bytes[slot] < bytes) {
+        if (ctx->sc_dev[slot]) (void)hipFree(ctx->sc_dev[slot]);
+        ctx->sc_dev[slot] = nullptr; ctx->sc_dev_bytes[slot] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->sc_dev[slot], want);
+        if (e != hipSuccess) return e;
+        ctx->sc_dev_bytes[slot] = want;
+    }
+    *out = ctx->sc_dev[slot];
+    return hipSuccess;
+}
+static hipError_t scratch_host(pgm_ctx *ctx, int slot, size_t bytes, void **out) {
+    bytes = std::max<size_t>(bytes, 16);
+    if (ctx->sc_host_bytes[slot] < bytes) {
+        if (ctx->sc_host[slot]) (void)hipHostFree(ctx->sc_host[slot]);
+        ctx->sc_host[slot] = nullptr; ctx->sc_host_bytes[slot] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipHostMalloc(&ctx->sc_host[slot], want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        ctx->sc_host_bytes[slot] = want;
+    }
+    *out = ctx->sc_host[slot];
+    return hipSuccess;
+}
+static hipError_t scratch_events(pgm_ctx *ctx) {
+    for (int k = 0; k < 2; ++k)
+        if (!ctx->sc_ev[k]) { hipError_t e = hipEventCreate(&ctx->sc_ev[k]); if (e != hipSuccess) return e; }
+    return hipSuccess;
 }
 
 static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {

@@ -3,21 +3,40 @@
 // every hot-path call fails loudly.
 #include "pgm_host.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace pgm {
 namespace {
 struct HipBackend : Backend {
+    // One context per device.  PGM_DEVICES="0,2,5" lists them explicitly, PGM_DEVICE=k selects one (what a one-process-
+    // per-GPU launcher sets), otherwise every visible device is used: context 0 runs the alignGraphs batches and the
+    // context profiles, all of them serve the all-pairs farm (computePwDistances, one host thread per context).
+    std::vector<pgm_ctx *> ctxs;
     pgm_ctx *ctx = nullptr;
     const CSProfile *loaded = nullptr;
     HipBackend() {
-        int dev = 0;
-        if (const char *e = getenv("PGM_DEVICE")) dev = atoi(e);
-        if (pgm_ctx_create(dev, &ctx) != PGM_OK || !ctx)
-            error("libpgm_hip: cannot create a context on device %d: %s", dev, pgm_last_error());
+        std::vector<int> devs;
+        if (const char *e = getenv("PGM_DEVICES")) {
+            for (const char *p = e; *p;) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        } else if (const char *e = getenv("PGM_DEVICE")) {
+            devs.push_back(atoi(e));
+        } else {
+            const int n = pgm_device_count();
+            for (int d = 0; d < std::max(n, 1); ++d) devs.push_back(d);
+        }
+        for (int d : devs) {
+            pgm_ctx *c = nullptr;
+            if (pgm_ctx_create(d, &c) != PGM_OK || !c)
+                error("libpgm_hip: cannot create a context on device %d: %s", d, pgm_last_error());
+            ctxs.push_back(c);
+        }
+        ctx = ctxs[0];
     }
-    ~HipBackend() override { if (ctx) pgm_ctx_destroy(ctx); }
+    ~HipBackend() override { for (pgm_ctx *c : ctxs) pgm_ctx_destroy(c); }
     const char *name() const override { return "hip"; }
+    int workers() const override { return (int)ctxs.size(); }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                             const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) override {
         int rc = pgm_align_graphs_batch(ctx, njobs, g1, g2, model, scores, out);
@@ -25,8 +44,8 @@ struct HipBackend : Backend {
     }
     void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
                         const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
-                        uint32_t *gaps) override {
-        int rc = pgm_nw_pairs_batch(ctx, dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps);
+                        uint32_t *gaps, int worker) override {
+        int rc = pgm_nw_pairs_batch(ctxs[(size_t)worker % ctxs.size()], dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps);
         if (rc != PGM_OK) error("pgm_nw_pairs_batch failed (%d): %s", rc, pgm_last_error());
     }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,

@@ -5,6 +5,7 @@
 #include "pgm_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <fstream>
@@ -133,9 +134,20 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
         }
         offs[i + 1] = (uint32_t)syms.size();
     }
+    // The reference's i < j double loop (DistanceFactoryAlign.h:35-53) is a farm of independent alignPair jobs.  Here: the
+    // pairs sorted by cost (longest first), cut into tiles, and one host thread per device context pulling tile numbers from
+    // an atomic counter (no collective, no static partition: a slower device simply takes fewer tiles).  Every tile is one
+    // pgm_nw_pairs_batch call on the worker's own context; the outputs of a pair land at the pair's position in the sorted
+    // order, whoever computed it, so the result does not depend on the number of workers.
     std::vector<uint32_t> pi, pj;
-    for (uint32_t i = 0; i < n; ++i)
-        for (uint32_t j = i + 1; j < n; ++j) { pi.push_back(i); pj.push_back(j); }
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> pr;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = i + 1; j < n; ++j) pr.push_back({i, j});
+        auto cost = [&](const std::pair<uint32_t, uint32_t> &p) { return (uint64_t)(offs[p.first + 1] - offs[p.first]) * (offs[p.second + 1] - offs[p.second]); };
+        std::stable_sort(pr.begin(), pr.end(), [&](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b2) { return cost(a) > cost(b2); });
+        for (auto &p : pr) { pi.push_back(p.first); pj.push_back(p.second); }
+    }
     const uint32_t np = (uint32_t)pi.size();
     std::vector<int32_t> counts((size_t)np * D * D);
     std::vector<uint32_t> gaps(np);
@@ -143,8 +155,29 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
     for (uint32_t p = 0; p < np; ++p)
         be.cells_nw += (uint64_t)(offs[pi[p] + 1] - offs[pi[p]]) * (offs[pj[p] + 1] - offs[pj[p]]);
     auto t0 = std::chrono::steady_clock::now();
-    be.nw_pairs_batch(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), np, pi.data(),
-                      pj.data(), counts.data(), gaps.data());
+    {
+        const int nw = std::max(1, be.workers());
+        // tile size: four tiles per worker (a tile should fill a device: its persistent grid holds ~7000 pairs at once), at
+        // least 256 pairs; PGM_NW_TILE overrides
+        uint32_t tile = std::max<uint32_t>(256u, (np + 4u * (uint32_t)nw - 1u) / (4u * (uint32_t)nw));
+        if (const char *e = getenv("PGM_NW_TILE")) tile = (uint32_t)std::max(1, atoi(e));
+        const uint32_t ntiles = np ? (np + tile - 1) / tile : 0;
+        std::atomic<uint32_t> next_tile(0);
+        auto farm = [&](int w) {
+            for (;;) {
+                const uint32_t t = next_tile.fetch_add(1);
+                if (t >= ntiles) break;
+                const uint32_t p0 = t * tile, cnt = std::min(tile, np - p0);
+                be.nw_pairs_batch(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), cnt, pi.data() + p0,
+                                  pj.data() + p0, counts.data() + (size_t)p0 * D * D, gaps.data() + p0, w);
+            }
+        };
+        std::vector<std::thread> devs;
+        for (int w = 1; w < nw; ++w) devs.emplace_back(farm, w);
+        farm(0);
+        for (auto &th : devs) th.join();
+        be.farm_workers = nw; be.farm_tiles = (int)ntiles;
+    }
     be.seconds_nw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     // ML distance per pair (Newton on d, each step a 20x20 P(d)): independent per pair, so the pairs are dealt to host
     // threads; every pair's arithmetic is the single-threaded one, the matrix entries written are disjoint

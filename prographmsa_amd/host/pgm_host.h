@@ -206,12 +206,16 @@ struct Backend {
     virtual void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                                     const pgm_model *const *model, const pgm_scores *scores,
                                     pgm_align_out *out) = 0;
+    // `worker` selects the device context (0 <= worker < workers()); calls with different workers may run concurrently
     virtual void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
                                 const int8_t *syms, const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
-                                const uint32_t *pj, int32_t *counts, uint32_t *gaps) = 0;
+                                const uint32_t *pj, int32_t *counts, uint32_t *gaps, int worker = 0) = 0;
+    // number of device contexts the all-pairs farm (computePwDistances) may drive, one host thread each
+    virtual int workers() const { return 1; }
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
                                         const uint64_t *out_offs) = 0;
+    int farm_workers = 0, farm_tiles = 0;   // what the last all-pairs farm used (logs / --stats)
     uint64_t cells_aligned = 0;   // Σ (n1-2)(n2-2)
     uint64_t cells_nw = 0;        // Σ L1*L2
     double seconds_align = 0, seconds_nw = 0, seconds_mldist = 0;

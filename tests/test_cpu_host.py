@@ -78,6 +78,25 @@ def test_job_dump_roundtrip_and_oracle_invariants(oracle_build, tmp_path):
         assert not np.any((m1 == 0xFFFFFFFF) & (m2 == 0xFFFFFFFF))
 
 
+@pytest.mark.parametrize("case,flags,gold", [("c1.fa", ["-a", "-m", "-T", "-i", "0"], "c1.nw_ml.tree"), ("c2.fa", ["-a", "-m", "-T", "-i", "0"], "c2.nw_ml.tree")])
+def test_all_pairs_farm_one_vs_k_workers(oracle_build, case, flags, gold):
+    """computePwDistances (host/distance.cpp) farms the alignPair tiles to one host thread per device context through an
+    atomic tile counter.  Same work queue with 1, 2, 3 and 5 workers and three tile sizes (oracle backend on the CPU; the
+    product binds the same code to one pgm_ctx per GPU): identical newick, identical to the reference binary's."""
+    exe = os.path.join(oracle_build, "pgmsa_oracle")
+    want = open(os.path.join(GOLD, gold)).read()
+    seen = set()
+    for workers, tile in ((1, 100000), (2, 7), (3, 5), (5, 64)):
+        env = dict(os.environ, PGM_FARM_WORKERS=str(workers), PGM_NW_TILE=str(tile))
+        r = subprocess.run([exe] + flags + ["--stats", os.path.join(GOLD, case)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want, (workers, tile)
+        st = [ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1]
+        assert '"farm_workers": %d' % workers in st
+        seen.add(r.stdout)
+    assert len(seen) == 1
+
+
 def test_random_job_generator_is_deterministic():
     from prographmsa_amd import jobs as J
     a, b = J.random_job(5, 30, 40, skip_frac=0.3, repeat_frac=0.1), J.random_job(5, 30, 40, skip_frac=0.3, repeat_frac=0.1)
@@ -85,12 +104,20 @@ def test_random_job_generator_is_deterministic():
     assert a.g1.r_col is not None or a.g2.r_col is not None
 
 
-def test_workqueue_partitions():
-    from prographmsa_amd import workqueue as wq
+def test_farm_partitions():
+    from prographmsa_amd import farm
     lengths = [5, 9, 2, 7, 7, 3, 11]
-    n = len(wq.all_pairs(len(lengths)))
+    pairs = farm.sorted_pairs(lengths)
+    assert sorted(pairs) == farm.all_pairs(len(lengths))
+    cost = [lengths[a] * lengths[b] for a, b in pairs]
+    assert cost == sorted(cost, reverse=True)
+    assert farm.tile_size(32640, 1) == 8160 and farm.tile_size(32640, 8) == 1020 and farm.tile_size(100, 8) == 256 and farm.tile_size(100, 8, "7") == 7
+    q = farm.TicketQueue("t", 1)
+    assert [q.next() for _ in range(4)] == [0, 1, 2, 3]
     for world in (1, 2, 3, 8):
-        seen = sorted(p for r in range(world) for p in wq.shard_pairs(lengths, r, world))
-        assert seen == list(range(n))
-        spans = [wq.shard_range(n, r, world) for r in range(world)]
-        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sh = farm.lpt_shards([9.0, 1.0, 4.0, 4.0, 2.0, 7.0, 3.0], world)
+        assert sorted(i for s_ in sh for i in s_) == list(range(7))
+        loads = [sum([9.0, 1.0, 4.0, 4.0, 2.0, 7.0, 3.0][i] for i in s_) for s_ in sh]
+        assert max(loads) <= 30.0 / world + 9.0
+        spans = [farm.shard_range(13, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 13 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
