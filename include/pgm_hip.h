@@ -153,6 +153,32 @@ int pgm_csprofile_create_batch(pgm_ctx *ctx, uint32_t nseq, const int8_t *syms,
                                const double *p_uniform, double *out, const uint64_t *out_offs);
 float pgm_csprofile_last_kernel_ms(pgm_ctx *ctx);
 
+/* ---- (f3) DistanceFactoryML::computeDistance / computeMLDist — replaces reference
+ * src/DistanceFactoryML.h:66-190 for a batch of pairs (the tail of computePwDistances, src/DistanceFactoryAlign.h:49-51,
+ * and of DistanceFactoryPrealigned, src/DistanceFactoryPrealigned.h:84-88).  The substitution model is handed over in the
+ * eigen form the reference builds in ModelFactory (src/ModelFactory.h:48-67): P(d) = V diag(exp(sigma d)) V^-1, all
+ * dim x dim matrices column-major double; dim <= 20.  min_dist / max_dist are the clamps of parseDistance
+ * (src/ModelFactory.h:125), dist_max / var_max / var_min the constants of DistanceFactoryML.cpp:3-32.
+ * counts[p * dim * dim + s1 + dim * s2], gaps[p], seqlen[p] = (L1 + L2) / 2 per pair -> dist[p], var[p]. */
+typedef struct pgm_mldist_model {
+    uint32_t dim;
+    const double *Q, *V, *Vi, *sigma;
+    double dist_max, var_max, var_min, cutoff_dist, min_dist, max_dist, indel_rate;
+    int32_t mldist, mldist_gap; /* cmdlineopts.mldist_flag / mldist_gap_flag */
+} pgm_mldist_model;
+int pgm_mldist_batch(pgm_ctx *ctx, const pgm_mldist_model *model, uint32_t npairs, const int32_t *counts,
+                     const uint32_t *gaps, const double *seqlen, double *dist, double *var);
+
+/* ---- (f3) DistanceFactoryPrealigned pair counts — replaces the column loop of reference
+ * src/DistanceFactoryPrealigned.h:34-90.  rows: nrows x ncols int8, row-major: ALPHABET::value() of a residue
+ * (0..dim-1), -1 for a gap, -2 for a residue without a value.  Only values < 20 are counted (the reference's literal 20).
+ * counts[p * dim * dim + s1 + dim * s2] and gaps[p] (gap openings) per pair (pi[p], pj[p]). */
+int pgm_prealigned_counts_batch(pgm_ctx *ctx, uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows,
+                                uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
+                                uint32_t *gaps);
+/* Device time of the kernel of the last pgm_mldist_batch / pgm_prealigned_counts_batch call on this context (ms). */
+float pgm_dist_last_kernel_ms(pgm_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,12 @@ class pgm_scores(C.Structure):
                                          "start_gap", "start_init", "repeat_init", "repeat_ext")]
 
 
+class pgm_mldist_model(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("Q", C.POINTER(C.c_double)), ("V", C.POINTER(C.c_double)), ("Vi", C.POINTER(C.c_double)),
+                ("sigma", C.POINTER(C.c_double))] + [(n, C.c_double) for n in ("dist_max", "var_max", "var_min", "cutoff_dist", "min_dist", "max_dist", "indel_rate")] \
+        + [("mldist", C.c_int32), ("mldist_gap", C.c_int32)]
+
+
 class pgm_align_out(C.Structure):
     _fields_ = [("score", C.c_float), ("n_tr_indels", C.c_uint32), ("len", C.c_uint32), ("status", C.c_int32),
                 ("map1", C.POINTER(C.c_uint32)), ("map2", C.POINTER(C.c_uint32))]
@@ -44,7 +50,7 @@ EXPORTS = [
     "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_last_kernel_ms", "pgm_csprofile_load", "pgm_csprofile_create_batch",
-    "pgm_csprofile_last_kernel_ms",
+    "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_dist_last_kernel_ms",
 ]
 
 
@@ -76,6 +82,9 @@ def _load():
         "pgm_csprofile_create_batch": (C.c_int, [vp, u32, C.POINTER(C.c_int8), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 4
                                        + [C.POINTER(C.c_uint64)]),
         "pgm_csprofile_last_kernel_ms": (C.c_float, [vp]),
+        "pgm_mldist_batch": (C.c_int, [vp, C.POINTER(pgm_mldist_model), u32, C.POINTER(i32), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 3),
+        "pgm_prealigned_counts_batch": (C.c_int, [vp, u32, u32, u32, C.POINTER(C.c_int8), u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),
+        "pgm_dist_last_kernel_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol

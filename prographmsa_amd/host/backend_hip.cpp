@@ -48,6 +48,18 @@ struct HipBackend : Backend {
         int rc = pgm_nw_pairs_batch(ctxs[(size_t)worker % ctxs.size()], dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps);
         if (rc != PGM_OK) error("pgm_nw_pairs_batch failed (%d): %s", rc, pgm_last_error());
     }
+    bool mldist_batch(const pgm_mldist_model &m, uint32_t npairs, const int32_t *counts, const uint32_t *gaps, const double *seqlen,
+                      double *dist, double *var, int worker) override {
+        int rc = pgm_mldist_batch(ctxs[(size_t)worker % ctxs.size()], &m, npairs, counts, gaps, seqlen, dist, var);
+        if (rc != PGM_OK) error("pgm_mldist_batch failed (%d): %s", rc, pgm_last_error());
+        return true;
+    }
+    bool prealigned_counts_batch(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
+                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps) override {
+        int rc = pgm_prealigned_counts_batch(ctx, dim, nrows, ncols, rows, npairs, pi, pj, counts, gaps);
+        if (rc != PGM_OK) error("pgm_prealigned_counts_batch failed (%d): %s", rc, pgm_last_error());
+        return true;
+    }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                 const double *tau, const double *pi, const double *p_uniform, double *out,
                                 const uint64_t *out_offs) override {

@@ -104,6 +104,66 @@ distvar_t DistanceFactoryML::computeDistance(const std::vector<int32_t> &counts,
     return distvar_t{dist, var};
 }
 
+static std::string g_dist_dump;
+void set_dist_dump(const std::string &path) { g_dist_dump = path; }
+static void dump_distances(const DistanceMatrix &d) {
+    if (g_dist_dump.empty()) return;
+    std::ofstream f(g_dist_dump.c_str(), std::ios::binary | std::ios::app);
+    const int32_t n = d.dim;
+    f.write((const char *)&n, 4);
+    f.write((const char *)d.distances.data(), 8 * d.distances.size());
+    f.write((const char *)d.variances.data(), 8 * d.variances.size());
+}
+
+void DistanceFactoryML::computeDistances(const std::vector<int32_t> &counts, const std::vector<uint32_t> &gaps, const std::vector<double> &seqlen,
+                                         const std::vector<uint32_t> &pi, const std::vector<uint32_t> &pj, DistanceMatrix &distances) const {
+    const uint32_t np = (uint32_t)pi.size(), D = (uint32_t)alphabet.DIM;
+    Backend &be = default_backend();
+    auto t1 = std::chrono::steady_clock::now();
+    bool done = false;
+    if (getenv("PGM_DEVICE_MLDIST") && model_factory->has_eigen() && D <= 20 && np) {
+        // the whole batch in one kernel (one wavefront per pair); same arithmetic as computeDistance below except for the
+        // device library's exp / log (last-bit differences: see csrc/pgm_dist_kernels.h)
+        double DIST_MAX, VAR_MAX, VAR_MIN;
+        consts(alphabet, DIST_MAX, VAR_MAX, VAR_MIN);
+        pgm_mldist_model m;
+        m.dim = D; m.Q = model_factory->Qmat().data(); m.V = model_factory->eigV().data(); m.Vi = model_factory->eigVi().data();
+        m.sigma = model_factory->eigSigma().data();
+        m.dist_max = DIST_MAX; m.var_max = VAR_MAX; m.var_min = VAR_MIN; m.cutoff_dist = cmdlineopts.cutoff_dist;
+        m.min_dist = cmdlineopts.min_dist; m.max_dist = cmdlineopts.max_dist; m.indel_rate = cmdlineopts.indel_rate;
+        m.mldist = cmdlineopts.mldist_flag ? 1 : 0; m.mldist_gap = cmdlineopts.mldist_gap_flag ? 1 : 0;
+        std::vector<double> dist(np), var(np);
+        done = be.mldist_batch(m, np, counts.data(), gaps.data(), seqlen.data(), dist.data(), var.data());
+        if (done)
+            for (uint32_t p = 0; p < np; ++p) {
+                distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dist[p];
+                distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = var[p];
+            }
+    }
+    if (!done) {
+        // ML distance per pair (Newton on d, each step a 20x20 P(d)): independent per pair, so the pairs are dealt to host
+        // threads; every pair's arithmetic is the single-threaded one, the matrix entries written are disjoint
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
+        nt = std::max(1u, std::min(nt, 16u));
+        nt = (unsigned)std::min<uint32_t>(nt, std::max(1u, np));
+        auto work = [&](unsigned t) {
+            std::vector<int32_t> c((size_t)D * D);
+            for (uint32_t p = t; p < np; p += nt) {
+                std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
+                distvar_t dv = computeDistance(c, gaps[p], seqlen[p]);
+                distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
+                distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+}
+
 // ---- DistanceFactoryAlign ---------------------------------------------------------------------
 DistanceFactoryAlign::DistanceFactoryAlign(const Alphabet &a, const ModelFactory *mf) : DistanceFactoryML(a, mf) {
     const int sd = a.DIM + 1;  // initMatrix (DistanceFactoryAlign.cpp:5-35, 38-235)
@@ -179,28 +239,10 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
         be.farm_workers = nw; be.farm_tiles = (int)ntiles;
     }
     be.seconds_nw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    // ML distance per pair (Newton on d, each step a 20x20 P(d)): independent per pair, so the pairs are dealt to host
-    // threads; every pair's arithmetic is the single-threaded one, the matrix entries written are disjoint
-    auto t1 = std::chrono::steady_clock::now();
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
-    nt = std::max(1u, std::min(nt, 16u));
-    nt = (unsigned)std::min<uint32_t>(nt, std::max(1u, np));
-    auto work = [&](unsigned t) {
-        std::vector<int32_t> c((size_t)D * D);
-        for (uint32_t p = t; p < np; p += nt) {
-            std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
-            double L1 = offs[pi[p] + 1] - offs[pi[p]], L2 = offs[pj[p] + 1] - offs[pj[p]];
-            distvar_t dv = computeDistance(c, gaps[p], (L1 + L2) / 2.0);
-            distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
-            distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
-        }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
-    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    std::vector<double> seqlen(np);
+    for (uint32_t p = 0; p < np; ++p) seqlen[p] = ((double)(offs[pi[p] + 1] - offs[pi[p]]) + (double)(offs[pj[p] + 1] - offs[pj[p]])) / 2.0;
+    computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    dump_distances(distances);
     return distances;
 }
 
@@ -320,47 +362,68 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     DistanceMatrix distances((int)n);
     std::vector<const sequence_t *> rows(n);
     for (uint32_t i = 0; i < n; ++i) rows[i] = &aligned.at(order[i]);
-    std::vector<std::pair<uint32_t, uint32_t>> pairs;
+    std::vector<uint32_t> pi, pj;
     for (uint32_t i = 0; i < n; ++i)
-        for (uint32_t j = i + 1; j < n; ++j) pairs.push_back({i, j});
+        for (uint32_t j = i + 1; j < n; ++j) { pi.push_back(i); pj.push_back(j); }
+    const uint32_t np = (uint32_t)pi.size();
+    const size_t L = n ? rows[0]->size() : 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (rows[i]->size() != L) error("prealigned distances: rows of different length");
+    std::vector<int32_t> counts((size_t)np * D * D, 0);
+    std::vector<uint32_t> gaps(np, 0);
     Backend &be = default_backend();
-    auto t1 = std::chrono::steady_clock::now();
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
-    nt = std::max(1u, std::min(nt, 16u));
-    nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, pairs.size()));
-    auto work = [&](unsigned t) {
-        std::vector<int32_t> counts((size_t)D * D);
-        for (size_t p = t; p < pairs.size(); p += nt) {
-            const sequence_t &s1 = *rows[pairs[p].first], &s2 = *rows[pairs[p].second];
-            if (s1.size() != s2.size()) error("prealigned distances: rows of different length");
-            std::fill(counts.begin(), counts.end(), 0);
-            index_t gaps = 0;
-            bool open1 = false, open2 = false;
-            for (size_t k = 0; k < s1.size(); ++k) {
-                const bool g1 = alphabet.isGap(s1[k]), g2 = alphabet.isGap(s2[k]);
-                if (!g1 && !g2) {
-                    const int c1 = alphabet.value(s1[k]), c2 = alphabet.value(s2[k]);
-                    if (c1 >= 0 && c1 < 20 && c2 >= 0 && c2 < 20) ++counts[(size_t)c1 + (size_t)D * c2];
-                    open1 = false; open2 = false;
-                } else if (g1 && g2) {
-                    // skip
-                } else if (!g1 && !open1) {
-                    ++gaps; open1 = true; open2 = false;
-                } else if (!g2 && !open2) {
-                    ++gaps; open1 = false; open2 = true;
-                }
+    bool done = false;
+    if (getenv("PGM_DEVICE_MLDIST") && np) {
+        // the N^2 L column scan on the device: value() per residue, -1 for a gap, -2 for a residue without a value
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<int8_t> mat((size_t)n * L);
+        for (uint32_t i = 0; i < n; ++i)
+            for (size_t k = 0; k < L; ++k) {
+                const int8_t c = (*rows[i])[k];
+                const int v = alphabet.isGap(c) ? -1 : alphabet.value(c);
+                mat[(size_t)i * L + k] = (int8_t)(alphabet.isGap(c) ? -1 : (v < 0 ? -2 : v));
             }
-            const distvar_t dv = computeDistance(counts, gaps, ((double)s1.size() + (double)s2.size()) / 2.0);
-            distances.D(pairs[p].first, pairs[p].second) = distances.D(pairs[p].second, pairs[p].first) = dv.dist;
-            distances.V(pairs[p].first, pairs[p].second) = distances.V(pairs[p].second, pairs[p].first) = dv.var;
-        }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
-    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        done = be.prealigned_counts_batch(D, n, (uint32_t)L, mat.data(), np, pi.data(), pj.data(), counts.data(), gaps.data());
+        be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!done) {
+        auto t1 = std::chrono::steady_clock::now();
+        unsigned nt = std::thread::hardware_concurrency();
+        if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
+        nt = std::max(1u, std::min(nt, 16u));
+        nt = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, np));
+        auto work = [&](unsigned t) {
+            for (size_t p = t; p < np; p += nt) {
+                const sequence_t &s1 = *rows[pi[p]], &s2 = *rows[pj[p]];
+                int32_t *c = counts.data() + p * D * D;
+                index_t g = 0;
+                bool open1 = false, open2 = false;
+                for (size_t k = 0; k < s1.size(); ++k) {
+                    const bool g1 = alphabet.isGap(s1[k]), g2 = alphabet.isGap(s2[k]);
+                    if (!g1 && !g2) {
+                        const int c1 = alphabet.value(s1[k]), c2 = alphabet.value(s2[k]);
+                        if (c1 >= 0 && c1 < 20 && c2 >= 0 && c2 < 20) ++c[(size_t)c1 + (size_t)D * c2];
+                        open1 = false; open2 = false;
+                    } else if (g1 && g2) {
+                        // skip
+                    } else if (!g1 && !open1) {
+                        ++g; open1 = true; open2 = false;
+                    } else if (!g2 && !open2) {
+                        ++g; open1 = false; open2 = true;
+                    }
+                }
+                gaps[p] = g;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool) th.join();
+        be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    }
+    std::vector<double> seqlen(np, ((double)L + (double)L) / 2.0);
+    computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    dump_distances(distances);
     return distances;
 }
 

@@ -16,7 +16,7 @@ using namespace pgm;
 static void usage() {
     std::cerr << "USAGE: pgmsa [-f|--fasta] [-t|--tree <newick>] [-o <file>] [-T] [-I] [-a] [-m] [-M]\n"
                  "             [--codon] [-c|--cs_profile <lib>] [-i <iters>] [-g rate] [-e prob] [-E prob]\n"
-                 "             [-s prob] [-A] [--dump_jobs <file>] [--stats] <fasta file>\n";
+                 "             [-s prob] [-A] [--dump_jobs <file>] [--dump_dist <file>] [--stats] <fasta file>\n";
 }
 
 static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &seqs,
@@ -87,7 +87,7 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
 int main(int argc, char **argv) {
     try {
         bool iters_set = false, stats = false, indel_set = false, edgehl_set = false, maxdist_set = false, cutdist_set = false;
-        std::string dump;
+        std::string dump, dist_dump;
         for (int i = 1; i < argc; ++i) {
             std::string s = argv[i];
             auto val = [&]() -> std::string { if (i + 1 >= argc) { usage(); exit(1); } return argv[++i]; };
@@ -114,6 +114,7 @@ int main(int argc, char **argv) {
             else if (s == "-p" || s == "--min_pdist") cmdlineopts.min_pdist = atof(val().c_str());
             else if (s == "-P" || s == "--max_pdist") cmdlineopts.max_pdist = atof(val().c_str());
             else if (s == "--dump_jobs") dump = val();
+            else if (s == "--dump_dist") dist_dump = val();
             else if (s == "--stats") stats = true;
             else if (s == "-h" || s == "--help") { usage(); return 0; }
             else if (!s.empty() && s[0] == '-') { std::cerr << "Command line error: unknown flag " << s << std::endl; return 1; }
@@ -129,6 +130,7 @@ int main(int argc, char **argv) {
         // main.cpp:243-246; this build also cannot iterate (see doAlign), so -a/-T runs behave as `-i 0`
         if (!iters_set && !cmdlineopts.tree_file.empty()) cmdlineopts.iters = 0;   // do not iterate when a guide tree is provided (main.cpp:243-246)
         if (!dump.empty()) set_job_dump(dump);
+        if (!dist_dump.empty()) set_dist_dump(dist_dump);
 
         std::vector<std::string> input_order;
         std::map<std::string, std::string> seqs = read_fasta(cmdlineopts.sequence_file, input_order);

@@ -103,6 +103,11 @@ public:
     int dim() const { return dim_; }
     const std::vector<double> &Qmat() const { return Q_; }
     const std::vector<double> &freqs() const { return freqs_; }
+    // eigen form P(d) = V diag(exp(sigma d)) V^-1 (only for reversible rate matrices: WAG)
+    bool has_eigen() const { return use_eigen_; }
+    const std::vector<double> &eigV() const { return V_; }
+    const std::vector<double> &eigVi() const { return Vi_; }
+    const std::vector<double> &eigSigma() const { return sigma_; }
 
 private:
     ModelFactory(int dim, const std::string &qmat_file);
@@ -212,6 +217,10 @@ struct Backend {
                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps, int worker = 0) = 0;
     // number of device contexts the all-pairs farm (computePwDistances) may drive, one host thread each
     virtual int workers() const { return 1; }
+    // batched DistanceFactoryML::computeDistance and the pair counts of an alignment on the device;
+    // false = this backend has no such kernel (the host estimator is used)
+    virtual bool mldist_batch(const pgm_mldist_model &, uint32_t, const int32_t *, const uint32_t *, const double *, double *, double *, int = 0) { return false; }
+    virtual bool prealigned_counts_batch(uint32_t, uint32_t, uint32_t, const int8_t *, uint32_t, const uint32_t *, const uint32_t *, int32_t *, uint32_t *) { return false; }
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
                                         const uint64_t *out_offs) = 0;
@@ -222,6 +231,7 @@ struct Backend {
 };
 Backend &default_backend();            // defined by exactly one backend_*.cpp linked into the program
 void set_job_dump(const std::string &path);  // if set, every alignGraphs job is appended to this file
+void set_dist_dump(const std::string &path); // if set, every distance matrix TreeNJ estimates is appended (dim, D, V as raw doubles)
 
 // alignGraphs (GraphAlign.h:200-534): one job; and the batched form the scheduler uses.
 AlignmentResult alignGraphs(const Graph &g1, const Graph &g2, const Model &model);
@@ -314,6 +324,10 @@ class DistanceFactoryML {   // DistanceFactoryML.h
 public:
     DistanceFactoryML(const Alphabet &a, const ModelFactory *mf) : alphabet(a), model_factory(mf) {}
     distvar_t computeDistance(const std::vector<int32_t> &counts, index_t gaps, double seqlen) const;  // :137-190
+    // computeDistance of every pair: on the device when PGM_DEVICE_MLDIST is set, the backend has the kernel and the model is
+    // in eigen form (20 states), else on host threads; fills the symmetric matrices
+    void computeDistances(const std::vector<int32_t> &counts, const std::vector<uint32_t> &gaps, const std::vector<double> &seqlen,
+                          const std::vector<uint32_t> &pi, const std::vector<uint32_t> &pj, DistanceMatrix &distances) const;
 protected:
     distvar_t computeMLDist(const std::vector<int32_t> &counts, index_t gaps, double seqlen, double dist0, double var0) const;  // :66-135
     Alphabet alphabet;
