@@ -221,6 +221,23 @@ def main():
         pmc = next((v for k, v in json.load(open(pmc_path)).items() if k.startswith("pgm_fill_kernel")), {})
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
+    pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+
+    def valu_roofline(kernel, launch_ms):
+        """VALU issue rate of a compute-bound satellite kernel: SQ_INSTS_VALU of one launch (profiles/r2_pmc.json, rocprofv3
+        --pmc pass of tools/profile_bench.sh) over the launch time measured live, against the chip's issue peak of one
+        wave64 VALU instruction per 2 cycles and SIMD (1024 SIMDs, 2.4 GHz nominal)."""
+        c = next((v for k, v in pmc_all.items() if k.startswith(kernel)), None)
+        if not c or "SQ_INSTS_VALU" not in c or launch_ms <= 0:
+            return None
+        insts = c["SQ_INSTS_VALU"]["mean"]
+        peak = 1024 * 2.4e9 / 2.0
+        return {"bound": "valu_issue", "achieved": round(insts / (launch_ms * 1e-3) / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+                "frac": round(insts / (launch_ms * 1e-3) / peak, 4), "valu_insts_per_launch": insts,
+                "lds_bank_conflict_cycles_per_lds_inst": round(c["SQ_LDS_BANK_CONFLICT"]["mean"] / max(c["SQ_INSTS_LDS"]["mean"], 1.0), 2),
+                "wave_cycles_split": {k: round(c[k]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c},
+                "source": pmc_name + " (SQ pass), launch time live (HIP events)"}
+
     roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
                 "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
@@ -298,6 +315,8 @@ def main():
                         "incl. H2D of the sequences and D2H of the 400-int count matrices; 2 direction bits/cell stored "
                         "(reference formulation: 12 B/cell)"}
     nw = all_pairs_stage(fam, "nw_c3")
+    if headline and world == 1:
+        nw["roofline"] = valu_roofline("pgm_nw_kernel", nw["rank0_kernel_ms"] / max(nw["tiles"], 1))
     nw_big = None
     if headline and not args.no_extra:
         nw_big = all_pairs_stage(gen.gen(1024, 600, 6), "nw_c5")
@@ -339,7 +358,8 @@ def main():
         cs_dt = max_over_ranks(time.perf_counter() - t0)
         cs_ms = float(pg.lib.pgm_csprofile_last_kernel_ms(ctx.handle))
         flop = 34.0 * K * L * nleaf   # ~K*L*34 flop per sequence (fp64)
-        cs = {"library": "synthetic K=%d x %d columns" % (K, ncols), "sequences_total": nleaf, "length": L, "wall_s": round(cs_dt, 4),
+        cs_roof = valu_roofline("pgm_csprofile_kernel", cs_ms) if world == 1 else None
+        cs = {"roofline": cs_roof, "library": "synthetic K=%d x %d columns" % (K, ncols), "sequences_total": nleaf, "length": L, "wall_s": round(cs_dt, 4),
               "rank0_kernel_ms": round(cs_ms, 3), "gflops_wall": round(flop / cs_dt / 1e9, 1), "scaling": "strong",
               "note": "whole pgm_csprofile_create_batch call incl. H2D of the residues and D2H of the 20 x (L+2) fp64 profiles; "
                       "reference config 5 spends ~450 s of 510 s in createProfile"}

@@ -1,15 +1,20 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): rocprofv3 kernel trace + two PMC passes over bench.py, then the summaries the
-# repository keeps under profiles/ (tools/summarize_profiles.py).  PMC passes are separate runs, as the MI355X guide asks.
+# Runs on the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes over bench.py, then the summaries the
+# repository keeps under profiles/ (tools/summarize_profiles.py).  PMC passes are separate runs with nothing but --pmc, as
+# the MI355X guide asks (FETCH_SIZE and WRITE_SIZE do not fit one pass; the SQ block has 8 slots).
+#   usage: tools/profile_bench.sh <tag>      e.g. r2
 set -e
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$1
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+B="python3 bench.py --warmup 1 --no-cpu-baseline --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B --steps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $B --steps 2 > /dev/null 2> "$OUT/fetch.err"
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- $B --steps 2 > /dev/null 2> "$OUT/write.err"
 echo "WRITE_SIZE pass done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq" -o run -- $B --steps 2 > /dev/null 2> "$OUT/sq.err"
+echo "SQ pass done"
 python3 tools/summarize_profiles.py "$OUT" "$1"
