@@ -90,3 +90,35 @@ def test_csprofile_matches_oracle(ctx):
         got = out[int(out_offs[s]): int(out_offs[s + 1])]
         assert np.all(np.isfinite(got))
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0)
+
+
+def test_csprofile_config5_scale_sample(ctx):
+    """BASELINE config 5 scale: the synthetic K = 4000 library and 1024 leaves x 600 residues of bench.py's `csprofile` record
+    (same generator, same seeds); every 64th leaf is compared with the oracle (the library streams through LDS in 250 chunks)."""
+    import oracle_lib
+    import prographmsa_amd as pg
+    rng = np.random.default_rng(5)
+    K, ncols, nleaf, L = 4000, 13, 1024, 600
+    p = rng.gamma(0.3, 1.0, (K, ncols, 20)) + 1e-4
+    p /= p.sum(2, keepdims=True)
+    w = 1.3 * 0.9 ** np.abs(np.arange(ncols) - ncols // 2)
+    lp = np.zeros((K, ncols, 21))
+    lp[:, :, :20] = np.log(p) * w[None, :, None]
+    lpf = np.ascontiguousarray(lp, np.float64).reshape(-1)
+    cf = np.ascontiguousarray(p[:, ncols // 2, :], np.float64).reshape(-1)
+    prf = np.log(rng.dirichlet(np.ones(K)))
+    syms = rng.integers(0, 20, nleaf * L).astype(np.int8)
+    offs = (np.arange(nleaf + 1) * L).astype(np.uint32)
+    out_offs = (np.arange(nleaf + 1) * 20 * (L + 2)).astype(np.uint64)
+    tau = np.full(nleaf, 0.3)
+    pi = np.full(20, 0.05)
+    pu = np.full(nleaf * 20, 0.05)
+    out = np.full(int(out_offs[-1]), np.nan)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    pg.check(pg.lib.pgm_csprofile_load(ctx.handle, K, ncols, P(lpf, C.c_double), P(cf, C.c_double), P(prf, C.c_double)))
+    pg.check(pg.lib.pgm_csprofile_create_batch(ctx.handle, nleaf, P(syms, C.c_int8), P(offs, C.c_uint32), P(tau, C.c_double),
+                                               P(pi, C.c_double), P(pu, C.c_double), P(out, C.c_double), P(out_offs, C.c_uint64)))
+    assert np.all(np.isfinite(out))
+    for s in range(0, nleaf, 64):
+        ref = oracle_lib.csprofile_create(K, ncols, lpf, cf, prf, syms[s * L:(s + 1) * L], 0.3, pi, pu[s * 20:(s + 1) * 20])
+        np.testing.assert_allclose(out[int(out_offs[s]): int(out_offs[s + 1])], ref, rtol=1e-12, atol=0)
