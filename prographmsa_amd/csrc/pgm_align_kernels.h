@@ -874,10 +874,13 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // MODE 2: merged graphs on the batch's critical path (PgmJob::mode2): this wavefront only evaluates the two terms that
 //         depend on the previous step (chain X, chain Y), merges the partial maxima three helper wavefronts have
 //         prepared a step ahead (pgm_terms_helper), stores the cell and records W, Y, X in the history
-template <int MODE>
+// DBG = false (production): no timeline accumulators, no experiment switches (their branches and scalar registers are gone)
+template <int MODE, bool DBG>
 __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *abort_flag, bool &aborted,
-                                               const uint32_t spin_limit, const bool stall, unsigned long long *wait_acc, int *sw_generic, const uint32_t dbg_flags) {
+                                               const uint32_t spin_limit, const bool stall, unsigned long long *wait_acc_, int *sw_generic, const uint32_t dbg_flags_) {
     constexpr bool NEAR = MODE == 1, HELPED = MODE == 2, EXTRAS = MODE != 0;
+    unsigned long long *const wait_acc = DBG ? wait_acc_ : nullptr;
+    const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
     constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF;
     constexpr int RS = HELPED ? 5 : 3;   // float4 per column of the ring: {q0, fd0-3, fc0-3}, or the whole node summary for the far helper
     typedef __attribute__((address_space(3))) int pgm_lds_int;
@@ -1425,11 +1428,14 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     }
 }
 
-// NOTRACEBACK = true: timing build for tools (the fill alone, no traceback)
-template <bool NOTRACEBACK>
+// NOTRACEBACK = true: timing build for tools (the fill alone, no traceback); DBG = true: timeline (PGM_FILL_TRACE) and the
+// experiment switches of PGM_TEST_NOSTORE
+template <bool NOTRACEBACK, bool DBG>
 __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace,
-                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags) {
+                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_) {
+    const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
+    if (!DBG) trace = nullptr;
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
     // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
     __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
@@ -1465,9 +1471,9 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helper
             const bool stall = item.job == stall_job && b == stall_band;
             uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
-            if (J.mode2) pgm_sweep_band<2>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, fsync, dbg_flags);
-            else if (J.has_extras) pgm_sweep_band<1>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
-            else pgm_sweep_band<0>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
+            if (J.mode2) pgm_sweep_band<2, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, fsync, dbg_flags);
+            else if (J.has_extras) pgm_sweep_band<1, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
+            else pgm_sweep_band<0, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
             if (trace && threadIdx.x == 0) { trace[6 * it] |= wait_ticks[0] << 16; if (!last_band) trace[6 * it + 4] = wait_ticks[1]; }   // (wavefront 0 of the worker; worker id in the low 16 bits)
         } else if (J.mode2 && !(dbg_flags & 4u)) {
             // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts

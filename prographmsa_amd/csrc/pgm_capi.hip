@@ -330,8 +330,9 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // timing experiments only (results are garbage): 1 = the cell stores are dropped, 2 = the sweeping wavefront of a MODE 2 band
     // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
     const uint32_t dbg_flags = getenv("PGM_TEST_NOSTORE") ? (uint32_t)atoi(getenv("PGM_TEST_NOSTORE")) : 0u;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
