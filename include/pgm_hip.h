@@ -179,6 +179,24 @@ int pgm_prealigned_counts_batch(pgm_ctx *ctx, uint32_t dim, uint32_t nrows, uint
 /* Device time of the kernel of the last pgm_mldist_batch / pgm_prealigned_counts_batch call on this context (ms). */
 float pgm_dist_last_kernel_ms(pgm_ctx *ctx);
 
+/* ---- (f1, numeric part) mergeGraphs' node profiles — replaces the P*g products and the L2 normalisation of reference
+ * src/GraphAlign.h:569-620 for a batch of merges (one per internal guide-tree node of a level,
+ * src/ProgressiveAlignment.h:449).  The caller walks the two mappings (the "unify" loops) and lists, per node of the
+ * merged graph, the source node in g1 / g2 (PGM_GAP if none) and whether the g2 node is propagated with model1.P (the
+ * reference does that for skipped g2 nodes, :591); the device returns the dim x nnodes profile matrix, bit-identical to
+ * the reference's arithmetic (Eigen gemv association, sequential norm, multiplication by the reciprocal).  The edge lists
+ * of the merged graph stay with the caller (host maps, O(edges)). */
+typedef struct pgm_merge_job {
+    uint32_t dim, n1, n2, nnodes;
+    const double *sites1, *sites2; /* Graph::sites of the two (uncleaned) graphs, dim x n column-major */
+    const double *P1, *P2;         /* model1.P, model2.P, dim x dim column-major */
+    const uint32_t *k1, *k2;       /* nnodes each */
+    const uint8_t *g2_with_P1;     /* nnodes */
+    double *profiles;              /* out: dim x nnodes column-major */
+} pgm_merge_job;
+int pgm_merge_profiles_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs);
+float pgm_merge_last_kernel_ms(pgm_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

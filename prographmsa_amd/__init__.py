@@ -39,6 +39,12 @@ class pgm_mldist_model(C.Structure):
         + [("mldist", C.c_int32), ("mldist_gap", C.c_int32)]
 
 
+class pgm_merge_job(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("n1", C.c_uint32), ("n2", C.c_uint32), ("nnodes", C.c_uint32),
+                ("sites1", C.POINTER(C.c_double)), ("sites2", C.POINTER(C.c_double)), ("P1", C.POINTER(C.c_double)), ("P2", C.POINTER(C.c_double)),
+                ("k1", C.POINTER(C.c_uint32)), ("k2", C.POINTER(C.c_uint32)), ("g2_with_P1", C.POINTER(C.c_uint8)), ("profiles", C.POINTER(C.c_double))]
+
+
 class pgm_align_out(C.Structure):
     _fields_ = [("score", C.c_float), ("n_tr_indels", C.c_uint32), ("len", C.c_uint32), ("status", C.c_int32),
                 ("map1", C.POINTER(C.c_uint32)), ("map2", C.POINTER(C.c_uint32))]
@@ -51,6 +57,7 @@ EXPORTS = [
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_last_kernel_ms", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_dist_last_kernel_ms",
+    "pgm_merge_profiles_batch", "pgm_merge_last_kernel_ms",
 ]
 
 
@@ -85,6 +92,8 @@ def _load():
         "pgm_mldist_batch": (C.c_int, [vp, C.POINTER(pgm_mldist_model), u32, C.POINTER(i32), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 3),
         "pgm_prealigned_counts_batch": (C.c_int, [vp, u32, u32, u32, C.POINTER(C.c_int8), u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),
         "pgm_dist_last_kernel_ms": (C.c_float, [vp]),
+        "pgm_merge_profiles_batch": (C.c_int, [vp, u32, C.POINTER(pgm_merge_job)]),
+        "pgm_merge_last_kernel_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol

@@ -20,6 +20,7 @@
 #include "pgm_nw_kernels.h"
 #include "pgm_csprofile_kernels.h"
 #include "pgm_dist_kernels.h"
+#include "pgm_merge_kernels.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
@@ -39,7 +40,7 @@ struct pgm_ctx {
     void *cache_ptr[C_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0, 0};
     hipDeviceProp_t prop;
-    float nw_ms = 0, cs_ms = 0, ml_ms = 0;
+    float nw_ms = 0, cs_ms = 0, ml_ms = 0, merge_ms = 0;
     // grow-only scratch buffers of the all-pairs / context-profile calls (slot = position in the call's buffer list): a
     // guide-tree stage issues many calls (one per pair tile), hipMalloc / hipFree of up to 2 GB per call would dominate them
     enum { SC_DEV = 24, SC_HOST = 4 };
@@ -765,3 +766,4 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
 #include "pgm_nw_capi.inc"
 #include "pgm_csprofile_capi.inc"
 #include "pgm_dist_capi.inc"
+#include "pgm_merge_capi.inc"

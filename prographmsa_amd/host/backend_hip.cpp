@@ -60,6 +60,11 @@ struct HipBackend : Backend {
         if (rc != PGM_OK) error("pgm_prealigned_counts_batch failed (%d): %s", rc, pgm_last_error());
         return true;
     }
+    bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs) override {
+        int rc = pgm_merge_profiles_batch(ctx, njobs, jobs);
+        if (rc != PGM_OK) error("pgm_merge_profiles_batch failed (%d): %s", rc, pgm_last_error());
+        return true;
+    }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                 const double *tau, const double *pi, const double *p_uniform, double *out,
                                 const uint64_t *out_offs) override {

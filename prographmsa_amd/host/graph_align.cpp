@@ -193,68 +193,66 @@ static void normalize(std::vector<double> &p) {  // p.norm()==0 ? p : p.normaliz
     for (double &v : p) v *= inv;
 }
 
-AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
-                            const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
-                            double support1, double support2) {
-    const int D = g1.dim();
+MergePlan planMerge(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1, const std::vector<index_t> &mapping2) {
     const index_t NONE = (index_t)-1;
-    std::vector<std::vector<double>> nodes;
-    nodes.reserve(g1.size() + g2.size());
-    Graph::EdgeMap edges;
-    Graph::RepeatMap repeats;
-    AncestralResult result;
-    std::vector<double> p, q;
-
+    MergePlan plan;
+    auto node = [&](index_t k1, index_t k2, bool matched, bool p1_for_g2) {
+        plan.mapping1.push_back(k1); plan.mapping2.push_back(k2);
+        plan.is_matched.push_back(matched); plan.g2_with_P1.push_back(p1_for_g2 ? 1 : 0);
+    };
     /* unify graphs (GraphAlign.h:569-620) */
     for (index_t i1 = 0, i2 = 0, j = 0; j < mapping1.size(); ++j) {
         index_t k1 = mapping1[j], k2 = mapping2[j];
         if (k1 != NONE) {
-            for (; i1 != k1; ++i1) {
-                matvec(model1.P, g1.col(i1), D, p);
-                normalize(p);
-                nodes.push_back(p);
-                result.mapping1.push_back(i1);
-                result.mapping2.push_back(NONE);
-                result.is_matched.push_back(false);
-            }
+            for (; i1 != k1; ++i1) node(i1, NONE, false, false);
             ++i1;
         }
         if (k2 != NONE) {
-            for (; i2 != k2; ++i2) {
-                matvec(model1.P, g2.col(i2), D, p);  // model1 (sic), GraphAlign.h:591
-                normalize(p);
-                nodes.push_back(p);
-                result.mapping1.push_back(NONE);
-                result.mapping2.push_back(i2);
-                result.is_matched.push_back(false);
-            }
+            for (; i2 != k2; ++i2) node(NONE, i2, false, true);   // model1 (sic), GraphAlign.h:591
             ++i2;
         }
+        if (k1 == NONE && k2 == NONE) error("error in mapping");
+        node(k1, k2, true, false);
+    }
+    (void)g1; (void)g2;
+    return plan;
+}
+
+void mergeProfilesHost(const Graph &g1, const Graph &g2, const Model &model1, const Model &model2, const MergePlan &plan,
+                       std::vector<double> &profiles) {
+    const int D = g1.dim();
+    const index_t NONE = (index_t)-1;
+    const size_t nn = plan.mapping1.size();
+    profiles.assign((size_t)D * nn, 0.0);
+    std::vector<double> p, q;
+    for (size_t v = 0; v < nn; ++v) {
+        const index_t k1 = plan.mapping1[v], k2 = plan.mapping2[v];
         if (k1 != NONE && k2 != NONE) {
             matvec(model1.P, g1.col(k1), D, p);
-            matvec(model2.P, g2.col(k2), D, q);
+            matvec(plan.g2_with_P1[v] ? model1.P : model2.P, g2.col(k2), D, q);
             for (int a = 0; a < D; ++a) p[a] *= q[a];
-            normalize(p);
-            nodes.push_back(p);
-            result.mapping1.push_back(k1);
-            result.mapping2.push_back(k2);
         } else if (k1 != NONE) {
             matvec(model1.P, g1.col(k1), D, p);
-            normalize(p);
-            nodes.push_back(p);
-            result.mapping1.push_back(k1);
-            result.mapping2.push_back(NONE);
-        } else if (k2 != NONE) {
-            matvec(model2.P, g2.col(k2), D, p);
-            normalize(p);
-            nodes.push_back(p);
-            result.mapping1.push_back(NONE);
-            result.mapping2.push_back(k2);
         } else {
-            error("error in mapping");
+            matvec(plan.g2_with_P1[v] ? model1.P : model2.P, g2.col(k2), D, p);
         }
-        result.is_matched.push_back(true);
+        normalize(p);
+        std::copy(p.begin(), p.end(), profiles.begin() + (size_t)D * v);
     }
+}
+
+AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const std::vector<double> &profiles,
+                            double support1, double support2) {
+    const int D = g1.dim();
+    const index_t NONE = (index_t)-1;
+    AncestralResult result;
+    result.mapping1 = plan.mapping1;
+    result.mapping2 = plan.mapping2;
+    result.is_matched = plan.is_matched;
+    std::vector<std::vector<double>> nodes(plan.mapping1.size());
+    for (size_t v = 0; v < nodes.size(); ++v) nodes[v].assign(profiles.begin() + (size_t)D * v, profiles.begin() + (size_t)D * (v + 1));
+    Graph::EdgeMap edges;
+    Graph::RepeatMap repeats;
 
     /* homologous path (GraphAlign.h:626-657) */
     index_t last_xy = 0, last_x = 0, last_y = 0, last_mapped = 0;
@@ -311,6 +309,15 @@ AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<
     }
     result.graph = Graph(D, nodes, edges, repeats);
     return result;
+}
+
+AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
+                            const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
+                            double support1, double support2) {
+    const MergePlan plan = planMerge(g1, g2, mapping1, mapping2);
+    std::vector<double> profiles;
+    mergeProfilesHost(g1, g2, model1, model2, plan, profiles);
+    return finishMerge(g1, g2, plan, profiles, support1, support2);
 }
 
 }  // namespace pgm

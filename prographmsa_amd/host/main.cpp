@@ -77,9 +77,9 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         Backend &be = default_backend();
         fprintf(stderr,
                 "{\"backend\": \"%s\", \"tree_s\": %.6f, \"progressive_s\": %.6f, \"align_cells\": %llu, \"align_s\": %.6f, "
-                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d}\n",
+                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"merge_profiles_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d}\n",
                 be.name(), t_tree, t_prog, (unsigned long long)be.cells_aligned, be.seconds_align,
-                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.farm_workers, be.farm_tiles);
+                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.seconds_merge_profiles, be.farm_workers, be.farm_tiles);
     }
     return 0;
 }

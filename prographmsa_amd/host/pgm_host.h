@@ -221,6 +221,9 @@ struct Backend {
     // false = this backend has no such kernel (the host estimator is used)
     virtual bool mldist_batch(const pgm_mldist_model &, uint32_t, const int32_t *, const uint32_t *, const double *, double *, double *, int = 0) { return false; }
     virtual bool prealigned_counts_batch(uint32_t, uint32_t, uint32_t, const int8_t *, uint32_t, const uint32_t *, const uint32_t *, int32_t *, uint32_t *) { return false; }
+    // node profiles of a batch of merged graphs on the device (numeric part); false = host arithmetic
+    virtual bool merge_profiles_batch(uint32_t, const pgm_merge_job *) { return false; }
+    double seconds_merge_profiles = 0;
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
                                         const uint64_t *out_offs) = 0;
@@ -239,6 +242,21 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
                                               const std::vector<const Graph *> &g2,
                                               const std::vector<const Model *> &model);
 // mergeGraphs (GraphAlign.h:550-727)
+// mergeGraphs in three parts, so that the profiles of all merges of a guide-tree level can be computed in one device batch:
+//   planMerge     the "unify" walk over the two mappings (GraphAlign.h:569-620 without the arithmetic): per node of the
+//                 merged graph its source nodes, whether a skipped g2 node is propagated with model1.P (:591), is_matched
+//   merge profiles  host: mergeProfilesHost; device: Backend::merge_profiles_batch (bit-identical)
+//   finishMerge   homologous path, inverse mappings, penalties, edge maps, Graph (:626-727)
+struct MergePlan {
+    std::vector<index_t> mapping1, mapping2;   // result.mapping1 / mapping2 (PGM_GAP = none)
+    std::vector<bool> is_matched;
+    std::vector<uint8_t> g2_with_P1;
+};
+MergePlan planMerge(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1, const std::vector<index_t> &mapping2);
+void mergeProfilesHost(const Graph &g1, const Graph &g2, const Model &model1, const Model &model2, const MergePlan &plan,
+                       std::vector<double> &profiles);   // dim x nnodes column-major
+AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const std::vector<double> &profiles,
+                            double support1, double support2);
 AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
                             const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
                             double support1, double support2);

@@ -162,6 +162,35 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         for (size_t k = 0; k < L; ++k) { g1[k] = pend[k].cg1.get(); g2[k] = pend[k].cg2.get(); mm[k] = &pend[k].model; }
         std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm);
         const auto tp2 = std::chrono::steady_clock::now();
+        // mergeGraphs of the whole level: plans on host threads, the node profiles (P g products, L2 normalisation: the
+        // arithmetic of the merge) in ONE device batch, then edges / Graph / extend_alignment on host threads again
+        std::vector<MergePlan> plans(L);
+        std::vector<std::vector<double>> profiles(L);
+        parallel_for(L, [&](size_t k) {
+            Node &nd = nodes[level[k]];
+            Pending &p = pend[k];
+            p.cg1->uncleanMapping(ar[k].mapping1);
+            p.cg2->uncleanMapping(ar[k].mapping2);
+            plans[k] = planMerge(nodes[nd.child[0]].res.graph, nodes[nd.child[1]].res.graph, ar[k].mapping1, ar[k].mapping2);
+            profiles[k].assign((size_t)a.DIM * plans[k].mapping1.size(), 0.0);
+        });
+        bool on_device = false;
+        if (!getenv("PGM_HOST_MERGE")) {
+            std::vector<pgm_merge_job> mj(L);
+            for (size_t k = 0; k < L; ++k) {
+                Node &nd = nodes[level[k]];
+                const Graph &ga = nodes[nd.child[0]].res.graph, &gb = nodes[nd.child[1]].res.graph;
+                pgm_merge_job &j = mj[k];
+                j.dim = (uint32_t)a.DIM; j.n1 = ga.size(); j.n2 = gb.size(); j.nnodes = (uint32_t)plans[k].mapping1.size();
+                j.sites1 = ga.col(0); j.sites2 = gb.col(0);
+                j.P1 = pend[k].model1.P.data(); j.P2 = pend[k].model2.P.data();
+                j.k1 = plans[k].mapping1.data(); j.k2 = plans[k].mapping2.data(); j.g2_with_P1 = plans[k].g2_with_P1.data();
+                j.profiles = profiles[k].data();
+            }
+            const auto tm0 = std::chrono::steady_clock::now();
+            on_device = default_backend().merge_profiles_batch((uint32_t)L, mj.data());
+            default_backend().seconds_merge_profiles += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
+        }
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
@@ -170,10 +199,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             result.score = ar[k].score;
             result.is_csprofile = false;
             result.n_tr_indels = ar[k].n_tr_indels + r1.n_tr_indels + r2.n_tr_indels;
-            p.cg1->uncleanMapping(ar[k].mapping1);
-            p.cg2->uncleanMapping(ar[k].mapping2);
-            AncestralResult anc = mergeGraphs(r1.graph, r2.graph, ar[k].mapping1, ar[k].mapping2, p.model1, p.model2,
-                                              (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
+            if (!on_device) mergeProfilesHost(r1.graph, r2.graph, p.model1, p.model2, plans[k], profiles[k]);
+            AncestralResult anc = finishMerge(r1.graph, r2.graph, plans[k], profiles[k], (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
             result.graph = anc.graph;
             extend_alignment(a, result, anc.mapping1, r1.aligned_sequences);
             extend_alignment(a, result, anc.mapping2, r2.aligned_sequences);
@@ -182,6 +209,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             r2 = ProgressiveAlignmentResult();
             p.cg1.reset();
             p.cg2.reset();
+            profiles[k] = std::vector<double>();
         });
         const auto tp3 = std::chrono::steady_clock::now();
         if (getenv("PGM_HOST_PROFILE"))
