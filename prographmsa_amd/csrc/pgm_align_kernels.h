@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 }
                 asm volatile("" ::: "memory");
             }
-            {   // operands of step t + 1 (their virtual-lane entries and column summaries were staged at least a block ago)
+            if (!(dbg_flags & 64u)) {   // operands of step t + 1 (their virtual-lane entries and column summaries were staged at least a block ago)
                 cn_n = ring3[((x + 1u) & (uint32_t)(NR - 1)) * (uint32_t)RS];
                 const uint32_t tm0 = (t & Dm) * HS, tm1 = ((t - 1u) & Dm) * HS, tm2 = ((t - 2u) & Dm) * HS;
                 inW1 = hW[tm0 + VL - 1]; inY1 = hY[tm0 + VL - 1];
@@ -1089,8 +1089,10 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 const float n2W = pgm_dpp_wave_shr1(u1W[sm1], iW2), n2Y = pgm_dpp_wave_shr1(u1Y, iY2);
                 u2W[s0] = n2W; u2Y = n2Y;
             }
-            u1W[s0] = pgm_dpp_wave_shr1(W_o, iW1);
-            u1Y = pgm_dpp_wave_shr1(Y_o, iY1);
+            if (!(dbg_flags & 128u)) {
+                u1W[s0] = pgm_dpp_wave_shr1(W_o, iW1);
+                u1Y = pgm_dpp_wave_shr1(Y_o, iY1);
+            } else { u1W[s0] = W_o; u1Y = Y_o; }
             auto mterm = [&](float w, float cy, float cx) { return __fsub_rn(__fsub_rn(__fadd_rn(w, S), cy), cx); };
             auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
             auto yterm = [&](float yp, float wp, float cy) { return __fsub_rn(fmaxf(__fadd_rn(yp, ge), __fadd_rn(wp, gopen_y)), cy); };
@@ -1467,6 +1469,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         const PgmJob &J = jobs[item.job];
         const uint32_t b = item.band + (uint32_t)role;
         const bool last_band = (item.band + item.count == J.nb);
+        const unsigned long long clk0 = (DBG && trace) ? __builtin_readcyclecounter() : 0ull;
         if ((uint32_t)role < item.count) {
             unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helper
             const bool stall = item.job == stall_job && b == stall_band;
@@ -1474,7 +1477,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             if (J.mode2) pgm_sweep_band<2, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, fsync, dbg_flags);
             else if (J.has_extras) pgm_sweep_band<1, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
             else pgm_sweep_band<0, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, nullptr, dbg_flags);
-            if (trace && threadIdx.x == 0) { trace[6 * it] |= wait_ticks[0] << 16; if (!last_band) trace[6 * it + 4] = wait_ticks[1]; }   // (wavefront 0 of the worker; worker id in the low 16 bits)
+            if (trace && threadIdx.x == 0) { trace[6 * it] |= wait_ticks[0] << 16; if (!last_band) { trace[6 * it + 4] = wait_ticks[1]; trace[6 * it + 5] = __builtin_readcyclecounter() - clk0; } }   // (wavefront 0 of the worker; worker id in the low 16 bits)
         } else if (J.mode2 && !(dbg_flags & 4u)) {
             // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts
             __builtin_amdgcn_s_setprio(0);

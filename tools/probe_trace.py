@@ -70,4 +70,6 @@ for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
     m = items[:, 0] == sel
     print("root job: bands %d, first start %.0f, last band end %.0f, tb end %.0f" % (m.sum(), start[m].min(), bend[m].max(), tend[m].max()))
     for i in np.where(m)[0][np.argsort(items[m][:, 1])]:
+        if tend[i] == 0 and raw[i, 5] > 0:
+            print("   band %2d: %.0f shader cycles in %.0f us = %.2f GHz" % (items[i, 1], float(raw[i, 5]), bend[i] - start[i], float(raw[i, 5]) / (bend[i] - start[i]) / 1e3))
         print("   band %2d: start %6.0f  wait %6.0f  end %6.0f  (running %.0f us = %.3f us/step; of which waiting for the helper %.0f us)" % (items[i, 1], start[i], wait_us[i], bend[i], bend[i] - start[i] - wait_us[i], (bend[i] - start[i] - wait_us[i]) / steps[i], raw[i, 4] / 100.0 if tend[i] == 0 else -1))
