@@ -1,6 +1,9 @@
 // graph_align.cpp — host side of reference src/GraphAlign.h: DynProgScores (:98-143),
 // the alignGraphs call surface (:200-534, executed by the backend behind the C ABI) and
 // mergeGraphs (:550-727) with the reference's quirks kept.
+// NOTE: planMerge / finishMerge below are DERIVED FROM reference src/GraphAlign.h:551-727 (mergeGraphs, restated with its quirks,
+// identifiers kept): host scaffolding around the device kernels; the arithmetic of the merge (node profiles) runs on the GPU
+// (csrc/pgm_merge_kernels.h), the edge bookkeeping here is the reference's.
 #include "pgm_host.h"
 
 #include <algorithm>

@@ -1,5 +1,8 @@
 // phytree.cpp — guide-tree container, newick reader/writer and FASTA IO
 // (reference src/PhyTree.{h,cpp}, src/newick.cpp, src/Fasta.cpp).  Host scaffolding only.
+// NOTE: maxDistPairR / midpointRoot below are DERIVED FROM reference src/PhyTree.cpp:11-116 (statement-for-statement restatement,
+// identifiers kept): host scaffolding outside SURVEY §8, needed only so that a FASTA / newick artefact can be produced
+// for the parity tests; it earns no coverage credit.
 #include "pgm_host.h"
 
 #include <algorithm>
