@@ -916,6 +916,8 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     const int nfyw = NEAR ? pgm_wave_max8(geny ? 0u : (fy & PGM_NF_COUNT)) : 0;
     const uint32_t xby = (uint32_t)J.xp1[yc], xey = (uint32_t)J.xp1[yc + 1];
     const float gopen_x = (rowvalid && y == 0) ? sg : gi;
+    const uint32_t ncol_row = rowvalid ? ncol : 0u;
+    const int x_init = (rowvalid && y == 0) ? 0 : -0x40000000;   // W(0,0) = start_init: only row 0 ever sees xs == x_init
     const bool has_next = (b + 1 < nb), has_prev = (b > 0);
     float4 *cells_band = J.cells + (size_t)b * tsteps * 64u;
     const __amdgpu_buffer_rsrc_t cells_rsrc = pgm_band_rsrc(cells_band, tsteps * 1024u);
@@ -1034,8 +1036,9 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
         for (int i = 0; i < BL; ++i) {
             const uint32_t t = t0 + i;
             const int xs = (int)t - lane;
-            const bool incol = xs >= 0 && xs < (int)ncol;
-            const bool active = rowvalid && incol;
+            // one unsigned compare per predicate, no mask arithmetic (a VALU compare combined on the scalar unit and fed back into a
+            // VALU select stalls the in-order wavefront twice): ncol_row = ncol for a valid row, 0 for the rows below the matrix
+            const bool active = (uint32_t)xs < ncol_row;
             const uint32_t x = (uint32_t)xs;
             const uint32_t rslot = (x & (uint32_t)(NR - 1)) * (uint32_t)RS;
             const float4 cn = cn_n;
@@ -1043,7 +1046,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             if (HELPED && !(dbg_flags & 2u)) {
                 // the helper wavefronts run ahead: normally their terms of this step are already published (no LDS access here)
                 const int want = (int)t + 1;
-                if (seenA < want || seenB < want || seenC < want) {
+                if (__builtin_expect(seenA < want || seenB < want || seenC < want, 0)) {
                     uint32_t spins = 0;
                     const unsigned long long h0 = wait_acc ? __builtin_amdgcn_s_memrealtime() : 0ull;
                     for (;;) {
@@ -1077,7 +1080,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             const float ccx = cn.x, c2x = EXTRAS ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
             const uint32_t fx = __float_as_uint(cn.w);
             const bool genx = EXTRAS && active && (fx & PGM_NF_GENERIC) != 0;
-            const bool xkill = active && (fx & PGM_NF_KILL) != 0;
+            const bool xkill = (fx & PGM_NF_KILL) != 0;
             const float gopen_y = (xs == 0) ? sg : gi;
             const float S = Sc[i];
             const int s0 = i & 3, sm1 = (i + 3) & 3, sm2 = (i + 2) & 3, sm3 = (i + 1) & 3;
@@ -1192,7 +1195,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             if (ykill) Xv = PGM_NEG_INF;
             if (xkill) Yv = PGM_NEG_INF;
             float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
-            if (rowvalid && y == 0 && xs == 0) Wv = s_init;
+            if (xs == x_init) Wv = s_init;
             if (!active) { Mv = PGM_NEG_INF; Xv = PGM_NEG_INF; Yv = PGM_NEG_INF; Wv = PGM_NEG_INF; }
             pgm_store_cell_masked(cells_rsrc, t, lane, active && !(dbg_flags & 1u), Mv, Xv, Wv, Yv);
             if (record && !(dbg_flags & 8u)) {
