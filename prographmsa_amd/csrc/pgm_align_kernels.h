@@ -928,6 +928,9 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     const float *resA = (const float *)(slot + J.aux_off + PGM_AUX_RES), *resB = resA + 768, *resC = resA + 1536;
     const bool use_far = has_far && !(dbg_flags & 16u);
     int seenA = (dbg_flags & 32u) ? 0x7fffffff : 0, seenB = use_far ? 0 : 0x7fffffff, seenC = seenB;   // HELPED: steps whose terms the helpers have published
+    const bool skipB = (dbg_flags & 256u) != 0, skipC = (dbg_flags & 512u) != 0;   // experiments: do not wait for that helper (wrong results)
+    if (skipB) seenB = 0x7fffffff;
+    if (skipC) seenC = 0x7fffffff;
 
     for (uint32_t i = (uint32_t)lane; i < D * HS; i += 64u) { hW[i] = PGM_NEG_INF; hY[i] = PGM_NEG_INF; }
     for (uint32_t i = (uint32_t)lane; i < DX * 64u; i += 64u) hX[i] = PGM_NEG_INF;
@@ -1052,8 +1055,8 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                     for (;;) {
                         if (!(dbg_flags & 32u)) seenA = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                         if (use_far) {
-                            seenB = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            seenC = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            if (!skipB) seenB = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            if (!skipC) seenC = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                         }
                         if (seenA >= want && seenB >= want && seenC >= want) break;
                         __builtin_amdgcn_s_sleep(1);
@@ -1254,12 +1257,26 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 // (groups 1 and 2 may run up to far_slack steps ahead of what is recorded.)  The wavefronts only meet through LDS words:
 // sw[0] = last step the sweeping wavefront has recorded + 2 (1 = its prologue is done), sw[1 + GROUP] = number of steps
 // whose terms are published.
-template <int GROUP>
-__device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic) {
-    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5;
+// LONG = true (PgmJob::long1 / long2): some entries are not in the LDS history — up to PGM_NLONG column entries farther than
+// PGM_DCAP (slots 7, 6, 5 of the column summary) or REMOTE row entries (farther than PGM_DCAP, or above the virtual lanes).
+// Their sources are read from the cell storage: they were stored at least 16 steps before the last recorded step, i.e.
+// before the sweeping wavefront's last counted wait (same band), or are covered by the progress of the band above.  The
+// loads of the regular pairs are issued PGM_PF steps ahead into register FIFOs, unconditionally (offset 0 when there is
+// nothing to load), so that the compiler can wait for them with counted waits; only (remote row x far column) and (far
+// row x long column) pairs are loaded on demand.  A long column entry travels down the lanes one step at a time like the
+// column itself, so a lane only loads the cell of its OWN row; W of the three rows above comes from the lanes above, one
+// step later each (the same systolic window as in the sweep; lanes 1-3 load lane 0's three rows of the band above).
+// Columns with more on-chip entries than the summary holds keep the rest in an overflow table (LDS copy, any helper).
+template <int GROUP, bool LONG>
+__device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic, const int slack_extra = 0) {
+    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5, PF = PGM_PF, NL = PGM_NLONG;
+    static_assert(PF == 4 && BL == 8, "FIFO slots are indexed with i & 3");
+    static_assert(PGM_DCAP + 1 - (4 + PF) >= 16 + 3, "a long source must be stored before the sweep's last counted wait");
     typedef __attribute__((address_space(3))) int pgm_lds_int;
+    typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
+    typedef uint32_t pgm_v2u __attribute__((ext_vector_type(2)));
     pgm_lds_int *sw = (pgm_lds_int *)sw_generic;
-    const uint32_t n1 = J.n1, tsteps = J.tsteps, nblk = J.nblk;
+    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nblk = J.nblk;
     const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap;
     const uint32_t D = J.hD, Dm = D - 1u, DX = J.hDX, DXm = DX - 1u;
     const float *hW = (const float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
@@ -1268,43 +1285,119 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     float *res = (float *)(aux + PGM_AUX_RES) + GROUP * 768, *sblk = (float *)(aux + PGM_AUX_SBLK);
     uint2 *elist = (uint2 *)(aux + PGM_AUX_EL);
     int *ecnt = (int *)(aux + PGM_AUX_CNT);
-    const int slack = GROUP == 0 ? 3 : (int)J.far_slack;
+    uint2 *ovtab = (uint2 *)(slot + J.ov_off);
+    const bool has_ov = GROUP != 0 && J.nov2 != 0;
+    const int slack = (GROUP == 0 ? 3 : (int)J.far_slack) + slack_extra;   // (slack_extra: timing experiments only, wrong results)
     const uint32_t y = 64u * b + (uint32_t)lane;
-    const bool rowvalid = y + 1 < n1;
+    const bool rowvalid = y + 1 < n1, has_prev = b > 0;
     const uint32_t yc = rowvalid ? y : 0u;
     const float4 *niq = (const float4 *)(J.ni1 + yc);
-    const float4 r0 = pgm_gload4(niq), r1 = pgm_gload4(niq + 1), r1b = pgm_gload4(niq + 2), r2 = pgm_gload4(niq + 3), r2b = pgm_gload4(niq + 4);
+    const float4 r0 = pgm_gload4(niq);
     const float ccy = r0.x;
     const uint32_t fy = rowvalid ? __float_as_uint(r0.w) : 0u;
-    const bool geny = (fy & PGM_NF_GENERIC) != 0 || ((fy & PGM_NF_COUNT) != 0 && ((fy >> 8) & 255u) > (uint32_t)(lane + VL));
+    const bool geny = (fy & PGM_NF_GENERIC) != 0;
     const float c2y = !geny ? r0.y : INFINITY, c3y = !geny ? r0.z : INFINITY;
     const float gopen_x = (rowvalid && y == 0) ? sg : gi;
+    const uint32_t ncol_row = rowvalid ? ncol : 0u;
     const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
     const uint32_t lb = (uint32_t)(VL + lane);
-    // GROUP 2: entry list of the band (order irrelevant).  LDS operations of one wavefront execute in order.
+    // cell (r, c) of the job = byte offset row_off(r) + c * 1024 into the job's cell storage (32-bit: the host only
+    // marks entries long / remote when the job's storage is smaller than 4 GiB)
+    const __amdgpu_buffer_rsrc_t job_rsrc = pgm_band_rsrc(J.cells, LONG ? J.nb * tsteps * 1024u : 16u);
+    auto row_off = [&](uint32_t r) { return (((r >> 6) * tsteps + (r & 63u)) * 64u + (r & 63u)) * 16u; };
+    auto load_w = [&](uint32_t off) {   // W of the cell at byte offset off (device-coherent like every read of another wavefront's cells)
+        const pgm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(job_rsrc, off + 8u, 0, 16);
+        return __uint_as_float(v.x);
+    };
+    if (has_ov) {   // (both far helpers copy the table: same values to the same words, no hand-shake needed)
+        for (uint32_t i = (uint32_t)lane; i < J.nov2 * (uint32_t)PGM_OV_ENT; i += 64u) ovtab[i] = make_uint2(pgm_gld(&J.ov2[i].x), pgm_gld(&J.ov2[i].y));
+    }
+    // GROUP 2: entry list of the band, remote entries first (order irrelevant otherwise).  LDS operations of one wavefront
+    // execute in order.
     int ne = 0;
     uint32_t e_o[KF], e_dy[KF];
     float e_cy[KF];
-    bool e_ok[KF];
+    bool e_ok[KF], e_rem[2] = {false, false};
+    uint32_t e_off[2] = {0u, 0u};
     if (GROUP == 2) {
         __hip_atomic_store(ecnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t cnt = (rowvalid && !geny) ? (fy & PGM_NF_COUNT) : 0u;
-        uint32_t base = 0;
-        if (cnt) base = (uint32_t)__hip_atomic_fetch_add(ecnt, (int)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const float dsrc[KF] = {r1.x, r1.y, r1.z, r1.w, r1b.x, r1b.y, r1b.z, r1b.w}, csrc[KF] = {r2.x, r2.y, r2.z, r2.w, r2b.x, r2b.y, r2b.z, r2b.w};
-#pragma unroll
-        for (int k = 0; k < KF; ++k)
-            if ((uint32_t)k < cnt) elist[base + k] = make_uint2((uint32_t)lane | (__float_as_uint(dsrc[k]) << 8), __float_as_uint(csrc[k]));
-        ne = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        __hip_atomic_store(ecnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int32_t f0 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc) : 0, f1 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc + 1) : 0;
+        uint32_t nrem = 0, nloc = 0;
+        for (int32_t e = f0; e < f1; ++e) { if (pgm_gld(&J.fe1[e].x) >> 31) ++nrem; else ++nloc; }
+        uint32_t baseR = 0, baseL = 0;
+        if (nrem) baseR = (uint32_t)__hip_atomic_fetch_add(ecnt, (int)nrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nloc) baseL = (uint32_t)__hip_atomic_fetch_add(ecnt + 1, (int)nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const int totL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        baseL += (uint32_t)totR;
+        for (int32_t e = f0; e < f1; ++e) {
+            const uint32_t dx = pgm_gld(&J.fe1[e].x), cb = pgm_gld(&J.fe1[e].y);
+            const uint32_t pos = (dx >> 31) ? baseR++ : baseL++;
+            if (pos < 512u) elist[pos] = make_uint2((uint32_t)lane | ((dx & 0x7fffffu) << 8) | (dx & 0x80000000u), cb);
+        }
+        ne = min(totR + totL, 512);   // (the host keeps a band within 512 entries and PGM_REMOTE_MAX remote ones)
 #pragma unroll
         for (int p = 0; p < KF; ++p) {
             const int idx = p * 64 + lane;
             e_ok[p] = idx < ne;
-            const uint2 a = e_ok[p] ? elist[idx] : make_uint2((uint32_t)lane, __float_as_uint(INFINITY));
-            e_o[p] = a.x & 255u; e_dy[p] = a.x >> 8; e_cy[p] = __uint_as_float(a.y);
+            const uint2 a = e_ok[p] ? elist[idx] : make_uint2((uint32_t)lane | (1u << 8), __float_as_uint(INFINITY));
+            e_o[p] = a.x & 255u; e_dy[p] = (a.x >> 8) & 0x7fffffu; e_cy[p] = __uint_as_float(a.y);
+            if (LONG && p < 2) {
+                e_rem[p] = (a.x >> 31) != 0;
+                if (e_rem[p]) e_off[p] = row_off(64u * b + e_o[p] - e_dy[p]);
+            }
         }
     }
     const int npass = (ne + 63) / 64;
+    // GROUP 2, LONG: {W, Y} of the source row of the remote entry of passes 0 and 1 at the columns x .. x + PF - 1 (FIFO) and W
+    // at x-1 .. x-3 (window)
+    float2 rf[2][PF];
+    float rw[2][4];
+    auto issue2 = [&](int p, int col, int slot_ix) {   // {W, Y} of the remote source of pass p at column col
+        const bool ok = e_rem[p] && (uint32_t)col < ncol;
+        const pgm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(job_rsrc, (ok ? e_off[p] + (uint32_t)col * 1024u : 0u) + 8u, 0, 16);
+        rf[p][slot_ix] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    };
+    // GROUP 1, LONG: per long slot s, X and W of the lane's row at the source column of the long entry of the columns
+    // x .. x + PF - 1 (FIFO), lane 0's three rows above in lanes 1-3 (FIFO), and the systolic window of the rows above
+    float fX[NL][PF], fW[NL][PF], fA[NL][PF], cW0[NL], cW1[NL], cW2[NL];
+    const uint32_t own_off = row_off(y);
+    const bool aux_ok = has_prev && lane >= 1 && lane <= 3;
+    const uint32_t aux_off = aux_ok ? row_off(64u * b - (uint32_t)lane) : 0u;
+    auto issue1 = [&](int xq, int slot_ix) {           // sources of the long entries of column xq, if it has any
+        const bool act = (uint32_t)xq < ncol_row;
+        const uint32_t rq = ((uint32_t)xq & (uint32_t)(NR - 1)) * (uint32_t)RS;
+        const uint32_t nl = act ? PGM_NF_NLONG(__float_as_uint(ring3[rq].w)) : 0u;
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (__builtin_amdgcn_ballot_w64(nl != 0u) != 0ull) dq = ring3[rq + 2u];
+#pragma unroll
+        for (int s = 0; s < NL; ++s) {
+            const bool has = nl > (uint32_t)s;
+            uint32_t off = 0u, aoff = 0u;
+            if (__builtin_amdgcn_ballot_w64(has) != 0ull) {
+                const uint32_t col = (uint32_t)xq - __float_as_uint(s == 0 ? dq.w : (s == 1 ? dq.z : dq.y));
+                off = has ? own_off + col * 1024u : 0u;
+                const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)col);      // lane 0's request
+                const bool has0 = __builtin_amdgcn_readfirstlane((int)has) != 0;
+                aoff = (has0 && aux_ok) ? aux_off + col0 * 1024u : 0u;
+            }
+            const pgm_v4u v = __builtin_amdgcn_raw_buffer_load_b128(job_rsrc, off, 0, 16);
+            fX[s][slot_ix] = __uint_as_float(v.y); fW[s][slot_ix] = __uint_as_float(v.z);
+            fA[s][slot_ix] = load_w(aoff);
+        }
+    };
+    if (LONG && GROUP == 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rw[p][k] = PGM_NEG_INF;
+        }
+    }
+    if (LONG && GROUP == 1) {
+#pragma unroll
+        for (int s = 0; s < NL; ++s) { cW0[s] = PGM_NEG_INF; cW1[s] = PGM_NEG_INF; cW2[s] = PGM_NEG_INF; }
+    }
     float4 pfs[BL / 4];
     auto load_s_block = [&](uint32_t s0) {
         const uint32_t tb = min(s0 / BL, nblk - 1u);
@@ -1313,6 +1406,18 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     };
     load_s_block(0);
     int seen = 0;
+    if (LONG && GROUP != 0) {   // the FIFOs are primed once the sweep's prologue is done (column ring staged)
+        while (seen < 1) {
+            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (seen < 1) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            if (GROUP == 1) issue1(s - lane, s);
+            else { issue2(0, s - (int)e_o[0], s); issue2(1, s - (int)e_o[1], s); }
+        }
+    }
     for (uint32_t t0 = 0; t0 < tsteps; t0 += BL) {
         float Sc[BL];
 #pragma unroll
@@ -1335,6 +1440,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             const uint32_t rslot = (((uint32_t)xs) & (uint32_t)(NR - 1)) * (uint32_t)RS;
             const float4 cn = ring3[rslot];
             float *rs = res + (t & 3u) * 192u;
+            const int s0 = i & 3, sm1 = (i + 3) & 3, sm2 = (i + 2) & 3, sm3 = (i + 1) & 3;
             if (GROUP == 0) {
                 const float S = Sc[i];
                 const float gopen_y = (xs == 0) ? sg : gi;
@@ -1360,8 +1466,19 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             } else if (GROUP == 1) {
                 const float S = Sc[i];
                 auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
+                auto mterm3 = [&](float W1, float W2, float W3, float cj) {
+                    return fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), cj), fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, S), c2y), cj), __fsub_rn(__fsub_rn(__fadd_rn(W3, S), c3y), cj)));
+                };
+                auto from_history = [&](uint32_t d, float cj, float &Mf, float &Xf) {   // entry at distance d (in the LDS history), cost cj
+                    const uint32_t s1 = t - d;
+                    const float Xh = hX[(s1 & DXm) * 64u + (uint32_t)lane], Wh = hW[(s1 & Dm) * HS + lb];
+                    const float W1 = hW[((s1 - 1u) & Dm) * HS + lb - 1u], W2 = hW[((s1 - 2u) & Dm) * HS + lb - 2u], W3 = hW[((s1 - 3u) & Dm) * HS + lb - 3u];
+                    Xf = fmaxf(Xf, xterm(Xh, Wh, cj));
+                    Mf = fmaxf(Mf, mterm3(W1, W2, W3, cj));
+                };
                 // ---- column entries, one row per lane ----
-                const uint32_t nfx = __float_as_uint(cn.w) & PGM_NF_COUNT;
+                const uint32_t fxw = (uint32_t)xs < ncol_row ? __float_as_uint(cn.w) : 0u;
+                const uint32_t nfx = fxw & PGM_NF_COUNT;
                 float Mf = PGM_NEG_INF, Xf = PGM_NEG_INF;
                 if (__builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull) {
                     const int nfxw = pgm_wave_max8(nfx);
@@ -1374,14 +1491,41 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 #pragma unroll
                     for (int j = 0; j < KF; ++j) {
                         if (j < nfxw) {
-                            const uint32_t s1 = t - fdx[j];
-                            const float Xh = hX[(s1 & DXm) * 64u + (uint32_t)lane], Wh = hW[(s1 & Dm) * HS + lb];
-                            const float W1 = hW[((s1 - 1u) & Dm) * HS + lb - 1u], W2 = hW[((s1 - 2u) & Dm) * HS + lb - 2u], W3 = hW[((s1 - 3u) & Dm) * HS + lb - 3u];
-                            Xf = fmaxf(Xf, xterm(Xh, Wh, fcx[j]));
-                            Mf = fmaxf(Mf, fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, S), ccy), fcx[j]),
-                                                 fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, S), c2y), fcx[j]), __fsub_rn(__fsub_rn(__fadd_rn(W3, S), c3y), fcx[j]))));
+                            const bool on = !LONG || (uint32_t)j < nfx;   // (LONG: the last slots may hold long entries, not in the history; else absent slots have cost +inf)
+                            from_history(on ? fdx[j] : 1u, on ? fcx[j] : INFINITY, Mf, Xf);
                         }
                     }
+                }
+                if (has_ov) {
+                    const uint32_t nov = PGM_NF_NOV(fxw), ovi = PGM_NF_OVI(fxw) * (uint32_t)PGM_OV_ENT;
+                    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nov) != 0ull; ++j) {
+                        const bool on = j < nov;
+                        const uint2 e = ovtab[on ? ovi + j : 0u];
+                        from_history(on ? e.x : 1u, on ? __uint_as_float(e.y) : INFINITY, Mf, Xf);
+                    }
+                }
+                if (LONG) {
+                    const uint32_t nlx = PGM_NF_NLONG(fxw);
+                    float4 cq = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                    if (__builtin_amdgcn_ballot_w64(nlx != 0u) != 0ull) cq = ring3[rslot + 4u];
+#pragma unroll
+                    for (int s = 0; s < NL; ++s) {
+                        const bool has = nlx > (uint32_t)s;
+                        if (__builtin_amdgcn_ballot_w64(has) != 0ull) {
+                            const float c7 = s == 0 ? cq.w : (s == 1 ? cq.z : cq.y);
+                            const float Xo = fX[s][s0], Wo = fW[s][s0], av = fA[s][s0];
+                            const float i1 = has_prev ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), 1)) : PGM_NEG_INF;
+                            const float i2 = has_prev ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), 2)) : PGM_NEG_INF;
+                            const float i3 = has_prev ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(av), 3)) : PGM_NEG_INF;
+                            const float W1 = pgm_dpp_wave_shr1(cW0[s], i1), W2 = pgm_dpp_wave_shr1(cW1[s], i2), W3 = pgm_dpp_wave_shr1(cW2[s], i3);
+                            if (has) {
+                                Xf = fmaxf(Xf, xterm(Xo, Wo, c7));
+                                Mf = fmaxf(Mf, mterm3(W1, W2, W3, c7));
+                            }
+                            cW0[s] = Wo; cW1[s] = W1; cW2[s] = W2;
+                        }
+                    }
+                    issue1(xs + PF, s0);
                 }
                 rs[lane] = Mf; rs[64 + lane] = Xf;
             } else {
@@ -1389,7 +1533,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                 // ---- row entries, one entry per lane ----
 #pragma unroll
                 for (int p = 0; p < KF; ++p) {
-                    if (p < npass) {
+                    const bool fifo = LONG && p < 2;   // (passes 0 and 1 keep their FIFOs moving even without entries)
+                    if (p < npass || fifo) {
                         const uint32_t o = e_o[p], dy = e_dy[p];
                         const float cy = e_cy[p];
                         const int xo = (int)t - (int)o;
@@ -1397,26 +1542,74 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                         const float4 cno = ring3[rso];
                         const float So = sblk[i * 64 + (int)o];
                         const float gopen_y = (xo == 0) ? sg : gi;
-                        const uint32_t s1 = t - dy, lp = (uint32_t)VL + o - dy;
-                        const float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
-                        const float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                        const bool rem = fifo && e_rem[p];
+                        const uint32_t s1 = t - dy, lp = rem ? 0u : (uint32_t)VL + o - dy;
+                        float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
+                        float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                        if (fifo) {
+                            const float2 cur = rf[p][s0];
+                            const bool cv = rem && (uint32_t)xo < ncol;
+                            const float Wr = cv ? cur.x : PGM_NEG_INF;
+                            rw[p][s0] = Wr;
+                            if (rem) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[p][sm1]; W2 = rw[p][sm2]; W3 = rw[p][sm3]; }
+                            issue2(p, xo + PF, s0);
+                        }
                         const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);
                         float Mt = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, So), cy), cno.x),
                                          fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, So), cy), cno.y), __fsub_rn(__fsub_rn(__fadd_rn(W3, So), cy), cno.z)));
-                        const uint32_t nfo = e_ok[p] ? (__float_as_uint(cno.w) & PGM_NF_COUNT) : 0u;
-                        if (__builtin_amdgcn_ballot_w64(nfo != 0u) != 0ull) {
+                        // ---- pairs with the far entries of the entry's current column ----
+                        const uint32_t fow = (e_ok[p] && (uint32_t)xo < ncol) ? __float_as_uint(cno.w) : 0u;
+                        const uint32_t nfo = fow & PGM_NF_COUNT, nlo = LONG ? PGM_NF_NLONG(fow) : 0u, novo = has_ov ? PGM_NF_NOV(fow) : 0u;
+                        if (__builtin_amdgcn_ballot_w64((nfo | nlo | novo) != 0u) != 0ull) {
                             const int nw = pgm_wave_max8(nfo);
                             const float4 g1 = ring3[rso + 1u], g2 = ring3[rso + 3u];
                             float4 g1b = make_float4(0.f, 0.f, 0.f, 0.f), g2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-                            if (nw > 4) { g1b = ring3[rso + 2u]; g2b = ring3[rso + 4u]; }
+                            if (nw > 4 || (LONG && __builtin_amdgcn_ballot_w64(nlo != 0u) != 0ull)) { g1b = ring3[rso + 2u]; g2b = ring3[rso + 4u]; }
                             const uint32_t gdx[KF] = {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w),
                                                       __float_as_uint(g1b.x), __float_as_uint(g1b.y), __float_as_uint(g1b.z), __float_as_uint(g1b.w)};
                             const float gcx[KF] = {g2.x, g2.y, g2.z, g2.w, g2b.x, g2b.y, g2b.z, g2b.w};
 #pragma unroll
                             for (int j = 0; j < KF; ++j) {
                                 if (j < nw) {
-                                    const float Wp = hW[((s1 - gdx[j]) & Dm) * HS + lp];
-                                    Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), gcx[j]));
+                                    const bool on = !LONG || ((uint32_t)j < nfo && !rem);
+                                    const float Wp = hW[((s1 - (on ? gdx[j] : 1u)) & Dm) * HS + lp];
+                                    Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), on ? gcx[j] : INFINITY));
+                                }
+                            }
+                            const uint32_t ovi = PGM_NF_OVI(fow) * (uint32_t)PGM_OV_ENT;
+                            if (has_ov) {
+                                for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < novo && !rem) != 0ull; ++j) {
+                                    const bool on = j < novo && !rem;
+                                    const uint2 e = ovtab[on ? ovi + j : 0u];
+                                    const float Wp = hW[((s1 - (on ? e.x : 1u)) & Dm) * HS + lp];
+                                    Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), on ? __uint_as_float(e.y) : INFINITY));
+                                }
+                            }
+                            if (LONG) {
+                                // pairs the history does not hold — (remote row, far column), (any far row, long column) — on demand:
+                                // the loads of the eight slots together, then the overflow entries of a remote row one by one
+                                const bool dem = (rem && (nfo | novo) != 0u) || nlo != 0u;
+                                if (__builtin_amdgcn_ballot_w64(dem) != 0ull) {
+                                    const uint32_t sb = rem ? e_off[p] : row_off(64u * b + o - dy);
+                                    float Wq[KF];
+                                    bool onq[KF];
+#pragma unroll
+                                    for (int j = 0; j < KF; ++j) {
+                                        const int col = xo - (int)gdx[j];
+                                        onq[j] = ((rem && (uint32_t)j < nfo) || (uint32_t)j >= (uint32_t)KF - nlo) && col >= 0;
+                                        Wq[j] = load_w(onq[j] ? sb + (uint32_t)col * 1024u : 0u);
+                                    }
+#pragma unroll
+                                    for (int j = 0; j < KF; ++j) Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(onq[j] ? Wq[j] : PGM_NEG_INF, So), cy), gcx[j]));
+                                    if (has_ov) {
+                                        for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(rem && j < novo) != 0ull; ++j) {
+                                            const bool on = rem && j < novo;
+                                            const uint2 e = ovtab[on ? ovi + j : 0u];
+                                            const int col = xo - (int)e.x;
+                                            const float Wp = load_w((on && col >= 0) ? sb + (uint32_t)col * 1024u : 0u);
+                                            Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn((on && col >= 0) ? Wp : PGM_NEG_INF, So), cy), on ? __uint_as_float(e.y) : INFINITY));
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -1484,10 +1677,15 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         } else if (J.mode2 && !(dbg_flags & 4u)) {
             // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts
             __builtin_amdgcn_s_setprio(0);
-            if (role == 1) { if (!(dbg_flags & 32u)) pgm_terms_helper<0>(J, item.band, L.pool, lane, fsync); }
+            if (role == 1) { if (!(dbg_flags & 32u)) pgm_terms_helper<0, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 1024u) ? 2 : 0); }
             else if (J.has_far && !(dbg_flags & 16u)) {
-                if (role == 2) pgm_terms_helper<1>(J, item.band, L.pool, lane, fsync);
-                else pgm_terms_helper<2>(J, item.band, L.pool, lane, fsync);
+                if (role == 2) {
+                    if (J.long2) pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                    else pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                } else {
+                    if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                    else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                }
             }
         }
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();

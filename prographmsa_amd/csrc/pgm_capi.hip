@@ -156,12 +156,20 @@ int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count
 // ---- flattening of one graph side -------------------------------------------------------------
 namespace {
 struct SideOff {
-    size_t sites, ni, xp, xc, xv, pp, pc, pv, pu;
+    size_t sites, ni, xp, xc, xv, pp, pc, pv, pu, fp, fe, ov;
     uint32_t nodes_with_extras;   // nodes with a predecessor other than the chain neighbour
+    uint32_t has_long;            // some edge outside the near slots is longer than PGM_DCAP
+    uint32_t maxd_cap;            // largest distance <= PGM_DCAP of an edge outside the chain slot (>= 1)
+    uint32_t maxd_kf8;            // ... among the nodes with at most PGM_KF8 far candidates, none of them long
+    // set by finalize_side, once the job's sweep mode is known:
     uint32_t far_nodes;           // nodes with entries served from the LDS history
     uint32_t maxd;                // largest on-chip predecessor distance of the graph (>= 1)
     uint32_t far_dmin;            // smallest distance of a far entry (PGM_DCAP + 1 if there is none)
-    uint32_t max_nfar;            // largest number of far entries of one node (<= PGM_KF8)
+    uint32_t remote;              // MODE 2: entries served from the cell storage by the far helpers
+    uint32_t nov;                 // MODE 2, columns: records of the overflow table in use
+    // host only: far candidates (every finite edge outside the near slots) of node v: [cp[v], cp[v+1])
+    std::vector<uint32_t> cp, cd;
+    std::vector<float> cv;
 };
 
 static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
@@ -171,26 +179,24 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
     std::vector<PgmNode2> ni(n);
-    o.nodes_with_extras = 0; o.far_nodes = 0; o.maxd = 1; o.far_dmin = PGM_DCAP + 1; o.max_nfar = 0;
+    o.nodes_with_extras = 0; o.has_long = 0; o.maxd_cap = 1; o.maxd_kf8 = 1;
+    o.cp.assign(n + 1, 0); o.cd.clear(); o.cv.clear();
     for (uint32_t v = 0; v < n; ++v) {
         PgmNode2 &I = ni[v];
         memset(&I, 0, sizeof I);
         I.cc = I.c2 = I.c3 = INFINITY;
         for (int k = 0; k < PGM_KF8; ++k) I.fc[k] = INFINITY;
-        uint32_t nfar = 0, dmax = 1;
-        bool generic = false;
-        // near slots: the first finite-cost edge from node-1 / node-2 / node-3; everything else is a far entry (an edge of
-        // infinite cost contributes -inf to every maximum: it only stays in the CSR lists)
+        // near slots: the first finite-cost edge from node-1 / node-2 / node-3; everything else is a far candidate (an edge
+        // of infinite cost contributes -inf to every maximum: it only stays in the CSR lists)
         auto place = [&](uint32_t from, float val) {
             const uint32_t d = v - from;
             if (d == 1 && I.cc == INFINITY && val != INFINITY) { I.cc = val; return; }
             xc.push_back(from); xv.push_back(val);
             if (val == INFINITY) return;
-            if (d == 2 && I.c2 == INFINITY) { I.c2 = val; dmax = std::max(dmax, d); return; }
-            if (d == 3 && I.c3 == INFINITY) { I.c3 = val; dmax = std::max(dmax, d); return; }
-            if (nfar >= (uint32_t)PGM_KF8 || d > (uint32_t)PGM_DCAP) { generic = true; return; }
-            I.fd[nfar] = d; I.fc[nfar] = val; ++nfar;
-            dmax = std::max(dmax, d);
+            if (d <= (uint32_t)PGM_DCAP) o.maxd_cap = std::max(o.maxd_cap, d); else o.has_long = 1;
+            if (d == 2 && I.c2 == INFINITY) { I.c2 = val; return; }
+            if (d == 3 && I.c3 == INFINITY) { I.c3 = val; return; }
+            o.cd.push_back(d); o.cv.push_back(val);
         };
         const int32_t eb = g->e_rowptr[v], ee = g->e_rowptr[v + 1];
         if (eb > ee || eb < 0) return PGM_ERR_INVALID;
@@ -215,16 +221,12 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
         }
         xp[v + 1] = (int32_t)xc.size();
         pp[v + 1] = (int32_t)pc.size();
-        if (generic) {   // every non-chain predecessor of this node goes through the CSR lists and the cell storage
-            I.c2 = I.c3 = INFINITY;
-            for (int k = 0; k < PGM_KF8; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
-            I.flags = PGM_NF_GENERIC | (1u << 8);
-        } else {
-            I.flags = nfar | (dmax << 8);
-            o.maxd = std::max(o.maxd, dmax);
-            o.far_nodes += nfar != 0;
-            o.max_nfar = std::max(o.max_nfar, nfar);
-            for (uint32_t k = 0; k < nfar; ++k) o.far_dmin = std::min(o.far_dmin, I.fd[k]);
+        o.cp[v + 1] = (uint32_t)o.cd.size();
+        {
+            uint32_t dm = I.c3 != INFINITY ? 3u : (I.c2 != INFINITY ? 2u : 1u);
+            bool small = o.cp[v + 1] - o.cp[v] <= (uint32_t)PGM_KF8;
+            for (uint32_t k = o.cp[v]; k < o.cp[v + 1] && small; ++k) { if (o.cd[k] > (uint32_t)PGM_DCAP) small = false; else dm = std::max(dm, o.cd[k]); }
+            if (small) o.maxd_kf8 = std::max(o.maxd_kf8, dm);
         }
         if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= PGM_NF_KILL;  // interior node without predecessors
         o.nodes_with_extras += (xp[v + 1] > xp[v]);
@@ -241,7 +243,86 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     o.pc = A.put(pc.data(), 4 * pc.size());
     o.pv = A.put(pv.data(), 4 * pv.size());
     o.pu = A.put(pu.data(), 4 * pu.size());
+    o.fp = A.put(nullptr, 4 * ((size_t)n + 1));                             // filled by finalize_side
+    o.fe = A.put(nullptr, 8 * std::max<size_t>(1, o.cd.size()));
+    o.ov = A.put(nullptr, 8 * (size_t)PGM_OV_REC * PGM_OV_ENT);
     return PGM_OK;
+}
+
+// Second half of the flattening, once the sweep mode of the job is known: where the far candidates of every node go.
+//   self-contained sweep (MODE 1): up to PGM_KF entries of distance <= PGM_DCAP in the node summary, else the node is generic
+//   MODE 2, rows (side 0): every candidate into the row CSR fp / fe, remote if farther than PGM_DCAP or above the virtual
+//           lanes of the row's band; at most PGM_REMOTE_MAX remote and 512 entries per band (rows beyond that: generic)
+//   MODE 2, columns (side 1): up to PGM_KF8 entries in the node summary, at most one of them LONG (slot 7)
+static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool mode2, bool allow_long, bool allow_ov) {
+    PgmNode2 *ni = (PgmNode2 *)(base + o.ni);
+    int32_t *fp = (int32_t *)(base + o.fp);
+    uint2 *fe = (uint2 *)(base + o.fe), *ov = (uint2 *)(base + o.ov);
+    o.nov = 0;
+    o.far_nodes = 0; o.maxd = 1; o.far_dmin = PGM_DCAP + 1; o.remote = 0;
+    uint32_t band_entries = 0, band_remote = 0, nfe = 0;
+    fp[0] = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+        PgmNode2 &I = ni[v];
+        const uint32_t kill = I.flags & PGM_NF_KILL;
+        const uint32_t c0 = o.cp[v], c1 = o.cp[v + 1], nc = c1 - c0;
+        if (side == 0 && (v & 63u) == 0) { band_entries = 0; band_remote = 0; }
+        uint32_t dmax = 1, nloc = 0, nrem = 0, novf = 0, ovi = 0;
+        if (I.c2 != INFINITY) dmax = 2;
+        if (I.c3 != INFINITY) dmax = 3;
+        bool generic = false;
+        if (!mode2) {
+            if (nc > (uint32_t)PGM_KF) generic = true;
+            for (uint32_t k = c0; k < c1 && !generic; ++k) {
+                if (o.cd[k] > (uint32_t)PGM_DCAP) { generic = true; break; }
+                I.fd[nloc] = o.cd[k]; I.fc[nloc] = o.cv[k]; ++nloc;
+                dmax = std::max(dmax, o.cd[k]);
+                o.far_dmin = std::min(o.far_dmin, o.cd[k]);
+            }
+        } else if (side == 0) {
+            const uint32_t lane = v & 63u;
+            for (uint32_t k = c0; k < c1; ++k) nrem += (o.cd[k] > (uint32_t)PGM_DCAP || o.cd[k] > lane + (uint32_t)PGM_VL);
+            if (band_entries + nc > 512u || band_remote + nrem > (uint32_t)PGM_REMOTE_MAX || nc > 255u || (nrem && !allow_long)) generic = true;
+            else {
+                for (uint32_t k = c0; k < c1; ++k) {
+                    const uint32_t d = o.cd[k];
+                    const bool rem = d > (uint32_t)PGM_DCAP || d > lane + (uint32_t)PGM_VL;
+                    fe[nfe++] = make_uint2(d | (rem ? 0x80000000u : 0u), __builtin_bit_cast(uint32_t, o.cv[k]));
+                    if (!rem) { dmax = std::max(dmax, d); o.far_dmin = std::min(o.far_dmin, d); ++nloc; }
+                }
+                band_entries += nc; band_remote += nrem;
+            }
+        } else {
+            for (uint32_t k = c0; k < c1; ++k) nrem += o.cd[k] > (uint32_t)PGM_DCAP;
+            const uint32_t nl_all = nc - nrem, ring_cap = (uint32_t)PGM_KF8 - std::min(nrem, (uint32_t)PGM_KF8);
+            novf = nl_all > ring_cap ? nl_all - ring_cap : 0u;
+            if (nrem > (uint32_t)PGM_NLONG || (nrem && !allow_long) || novf > (uint32_t)PGM_OV_ENT || (novf && (o.nov >= (uint32_t)PGM_OV_REC || !allow_ov))) generic = true;
+            else {
+                uint2 *rec = ov + (size_t)o.nov * PGM_OV_ENT;
+                uint32_t nl = 0, no = 0;
+                for (uint32_t k = c0; k < c1; ++k) {
+                    const uint32_t d = o.cd[k];
+                    if (d > (uint32_t)PGM_DCAP) { I.fd[PGM_KF8 - 1 - nl] = d; I.fc[PGM_KF8 - 1 - nl] = o.cv[k]; ++nl; continue; }
+                    if (nloc < ring_cap) { I.fd[nloc] = d; I.fc[nloc] = o.cv[k]; ++nloc; }
+                    else rec[no++] = make_uint2(d, __builtin_bit_cast(uint32_t, o.cv[k]));
+                    dmax = std::max(dmax, d); o.far_dmin = std::min(o.far_dmin, d);
+                }
+                if (novf) { ovi = o.nov++; for (; no < (uint32_t)PGM_OV_ENT; ++no) rec[no] = make_uint2(1u, __builtin_bit_cast(uint32_t, (float)INFINITY)); }
+            }
+        }
+        fp[v + 1] = (int32_t)nfe;
+        if (generic) {   // every non-chain predecessor of this node goes through the CSR lists and the cell storage
+            I.c2 = I.c3 = INFINITY;
+            for (int k = 0; k < PGM_KF8; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
+            I.flags = PGM_NF_GENERIC | (1u << 8) | kill;
+        } else {
+            const bool rows2 = mode2 && side == 0;
+            I.flags = (rows2 ? 0u : nloc) | (dmax << 8) | kill | ((mode2 && side == 1) ? (nrem << 16) | (novf << 20) | (ovi << 25) : 0u);
+            o.maxd = std::max(o.maxd, dmax);
+            o.far_nodes += (nloc + nrem) != 0;
+            o.remote += nrem;
+        }
+    }
 }
 
 // take a buffer of at least `bytes` from the context's cache slot, or allocate one (device memory; slot C_HOST: pinned host)
@@ -363,7 +444,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         size_t E = (size_t)std::max(0, g->e_rowptr ? g->e_rowptr[n] : 0);
         if (g->r_rowptr) E += (size_t)std::max(0, g->r_rowptr[n]);
         E = std::max<size_t>(E, 1);
-        return n * g->dim * 8 + n * sizeof(PgmNode2) + 2 * (n + 1) * 4 + E * 20 + 16 * 16;
+        return n * g->dim * 8 + n * sizeof(PgmNode2) + 3 * (n + 1) * 4 + E * 28 + 8 * (size_t)PGM_OV_REC * PGM_OV_ENT + 16 * 16;
     };
     std::vector<size_t> in_base(njobs + 1, 0);
     for (uint32_t i = 0; i < njobs; ++i) {
@@ -417,6 +498,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     {
         std::atomic<int> bad(-1);
         std::atomic<uint32_t> next_job(0);
+        const bool job_stats = getenv("PGM_JOB_STATS") != nullptr;                                  // tools only
         const bool no_helper = getenv("PGM_NO_HELPER") != nullptr;                                  // experiments only
         const int mode2_min_bands = getenv("PGM_MODE2_BANDS") ? atoi(getenv("PGM_MODE2_BANDS")) : 20;   // experiments only
         auto work = [&]() {
@@ -429,35 +511,59 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 Off &o = off[i];
                 if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); continue; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
-                J.has_far = (o.s1.far_nodes + o.s2.far_nodes) > 0 ? 1u : 0u;
                 // LDS of one sweeping wavefront: W / Y history of hD steps x (64 lanes + 16 virtual lanes), X history of hDX
                 // steps x 64 lanes, 128 column summaries.  A pair (y - dy, x - dx) is read dy + dx steps back and the virtual
                 // lanes are written a block ahead: hD >= maxd1 + maxd2 + 8, hDX >= maxd2 + 1 (powers of two).
                 uint32_t hD = 16, hDX = 4;
-                while (hD < o.s1.maxd + o.s2.maxd + (uint32_t)PGM_BLOCK) hD *= 2;
-                while (hDX < o.s2.maxd + 1) hDX *= 2;
+                while (hD < o.s1.maxd_kf8 + o.s2.maxd_kf8 + (uint32_t)PGM_BLOCK) hD *= 2;
+                while (hDX < o.s2.maxd_kf8 + 1) hDX *= 2;
+                // Jobs on the batch's critical path (many bands, or a deep history that leaves room for one or two sweeps per
+                // worker anyway) and jobs with edges longer than the on-chip history are swept one band per worker: the other
+                // three wavefronts take every term but the chain terms off the sweeping wavefront (pgm_terms_helper), which
+                // shortens its step by a factor of 2-3, and serve the long edges from the cell storage with a prefetch.
+                const uint32_t nb_job = (g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
+                // (the helpers address the job's cell storage with 32-bit byte offsets)
+                const bool allow_long = !getenv("PGM_NO_LONG") && (uint64_t)J.nb * J.tsteps * 1024u < (1ull << 32);
+                const bool has_long = (o.s1.has_long | o.s2.has_long) != 0 && allow_long;
+                J.mode2 = (J.has_extras && (hD >= 32u || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
+                if (J.mode2) {   // (a MODE 2 sweep keeps every on-chip distance of the graphs, whatever the number of entries of a node)
+                    while (hD < o.s1.maxd_cap + o.s2.maxd_cap + (uint32_t)PGM_BLOCK) hD *= 2;
+                    while (hDX < o.s2.maxd_cap + 1) hDX *= 2;
+                }
                 J.hD = hD; J.hDX = hDX;
                 J.slot_bytes = 2u * hD * (64u + PGM_VL) * 4u + hDX * 64u * 4u;
-                // Jobs on the batch's critical path (many bands, or a deep history that leaves room for one or two sweeps per
-                // worker anyway) are swept one band per worker: the other three wavefronts take every term but the two chain
-                // terms off the sweeping wavefront (pgm_terms_helper), which shortens its step by a factor of 2-3.
-                const uint32_t nb_job = (g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
-                J.mode2 = (J.has_extras && (hD >= 32u || nb_job >= (uint32_t)mode2_min_bands) && !no_helper) ? 1u : 0u;
-                J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.slot_bytes += PGM_NRING * (J.mode2 ? 80u : 48u);   // column ring: 5 or 3 float4 per column
                 J.aux_off = J.slot_bytes;
                 if (J.mode2) J.slot_bytes += PGM_AUX_BYTES;
+                const uint32_t ov_bytes = 8u * PGM_OV_REC * PGM_OV_ENT;
+                finalize_side(b->h_in, g1[i]->n, o.s1, 0, J.mode2 != 0, allow_long, false);
+                finalize_side(b->h_in, g2[i]->n, o.s2, 1, J.mode2 != 0, allow_long, J.slot_bytes + ov_bytes <= (uint32_t)PGM_POOL);
+                J.nov2 = J.mode2 ? o.s2.nov : 0u;
+                J.ov_off = J.slot_bytes;
+                if (J.nov2) J.slot_bytes += ov_bytes;
+                J.has_far = (o.s1.far_nodes + o.s2.far_nodes) > 0 ? 1u : 0u;
+                J.long1 = (J.mode2 && o.s1.remote) ? 1u : 0u;
+                J.long2 = (J.mode2 && o.s2.remote) ? 1u : 0u;
+                J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.nslots = J.mode2 ? 1u : std::max(1u, std::min(4u, (uint32_t)PGM_POOL / J.slot_bytes));
-                if (!J.mode2 && std::max(o.s1.max_nfar, o.s2.max_nfar) > (uint32_t)PGM_KF) {
-                    // a self-contained sweep serves PGM_KF far edges per node: nodes with more become generic
+                if (job_stats) {   // tools: how the nodes of this job are served
+                    uint32_t gen[2] = {0, 0}, lng = 0;
                     for (int side = 0; side < 2; ++side) {
-                        PgmNode2 *ni = (PgmNode2 *)(b->h_in + (side ? o.s2.ni : o.s1.ni));
+                        const PgmNode2 *ni = (const PgmNode2 *)(b->h_in + (side ? o.s2.ni : o.s1.ni));
+                        const uint32_t nn = side ? g2[i]->n : g1[i]->n;
+                        for (uint32_t v = 0; v < nn; ++v) { gen[side] += (ni[v].flags & PGM_NF_GENERIC) != 0; if (side) lng += PGM_NF_NLONG(ni[v].flags); }
+                    }
+                    fprintf(stderr, "pgm job %u: %u x %u mode2 %u hD %u hDX %u far_slack %u generic rows %u cols %u remote row entries %u long col entries %u far nodes %u + %u overflow cols %u\n",
+                            i, g1[i]->n, g2[i]->n, J.mode2, J.hD, J.hDX, J.far_slack, gen[0], gen[1], o.s1.remote, lng, o.s1.far_nodes, o.s2.far_nodes, J.nov2);
+                    for (int side = 0; side < 2; ++side) {
+                        const SideOff &so = side ? o.s2 : o.s1;
+                        const PgmNode2 *ni = (const PgmNode2 *)(b->h_in + so.ni);
                         const uint32_t nn = side ? g2[i]->n : g1[i]->n;
                         for (uint32_t v = 0; v < nn; ++v)
-                            if ((ni[v].flags & PGM_NF_COUNT) > (uint32_t)PGM_KF && !(ni[v].flags & PGM_NF_GENERIC)) {
-                                ni[v].c2 = ni[v].c3 = INFINITY;
-                                for (int k = 0; k < PGM_KF8; ++k) { ni[v].fd[k] = 0; ni[v].fc[k] = INFINITY; }
-                                ni[v].flags = PGM_NF_GENERIC | (1u << 8) | (ni[v].flags & PGM_NF_KILL);
+                            if (ni[v].flags & PGM_NF_GENERIC) {
+                                uint32_t nl = 0;
+                                for (uint32_t k = so.cp[v]; k < so.cp[v + 1]; ++k) nl += so.cd[k] > (uint32_t)PGM_DCAP;
+                                fprintf(stderr, "   generic %s %u: %u far candidates, %u of them long\n", side ? "col" : "row", v, so.cp[v + 1] - so.cp[v], nl);
                             }
                     }
                 }
@@ -511,6 +617,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.xp1 = (const int32_t *)(in + o.s1.xp); J.xp2 = (const int32_t *)(in + o.s2.xp);
         J.xc1 = (const uint32_t *)(in + o.s1.xc); J.xc2 = (const uint32_t *)(in + o.s2.xc);
         J.xv1 = (const float *)(in + o.s1.xv); J.xv2 = (const float *)(in + o.s2.xv);
+        J.fp1 = (const int32_t *)(in + o.s1.fp); J.fe1 = (const uint2 *)(in + o.s1.fe);
+        J.ov2 = (const uint2 *)(in + o.s2.ov);
         J.pp1 = (const int32_t *)(in + o.s1.pp); J.pp2 = (const int32_t *)(in + o.s2.pp);
         J.pc1 = (const uint32_t *)(in + o.s1.pc); J.pc2 = (const uint32_t *)(in + o.s2.pc);
         J.pv1 = (const float *)(in + o.s1.pv); J.pv2 = (const float *)(in + o.s2.pv);

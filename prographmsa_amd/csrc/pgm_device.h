@@ -12,13 +12,15 @@
 #define PGM_NRING 128      /* columns of graph 2 whose predecessor summary is kept in LDS per sweeping wavefront */
 #define PGM_KF 4           /* "far" predecessors per node served from the LDS history by a self-contained sweep (MODE 1) */
 #define PGM_KF8 8          /* ... by the far helper of a MODE 2 sweep */
-#define PGM_DCAP 28        /* largest predecessor distance served on chip (farther: generic path through the cell storage) */
+#define PGM_DCAP 28        /* largest predecessor distance served from the on-chip history (farther: cell storage) */
+#define PGM_PF 4           /* MODE 2: the far helpers load the sources of long / remote entries this many steps ahead */
+#define PGM_REMOTE_MAX 128 /* MODE 2: remote row entries per band served by the far helper (two per lane) */
 #define PGM_POOL 81408     /* LDS bytes of a fill worker (two workers per CU: 2 x (81408 + 512) = 160 KiB) */
 /* extra LDS of a MODE 2 sweep (PgmJob::mode2: three helper wavefronts evaluate all but the chain terms), at PgmJob::aux_off: */
 #define PGM_AUX_RES 0      /* float res[3 groups][4][3][64]: partial maxima {M, X, Y} per lane of the steps t & 3, per helper group */
 #define PGM_AUX_SBLK 9216  /* float sblk[8][64]: emission scores of the far helper's current block (entry lanes read their owner's) */
 #define PGM_AUX_EL 11264   /* uint2 elist[512]: far row entries of the band {owner lane | distance << 8, cost} */
-#define PGM_AUX_CNT 15360  /* int: number of entries */
+#define PGM_AUX_CNT 15360  /* int[2]: number of remote entries, number of local entries */
 #define PGM_AUX_BYTES 15376
 
 // Per-node predecessor summary prepared by the host from the CSR (80 bytes = 5 float4).
@@ -31,11 +33,24 @@
 //          bit 4   : generic — more far edges than that or a distance > PGM_DCAP: every non-chain predecessor of this
 //                    node is read from the cell storage through the CSR lists (xp/xc/xv); then c2 = c3 = +inf, no far entries
 //          bit 5   : kill — interior node without any predecessor
+//          MODE 2, columns only:
+//          bits 16-17: number of LONG entries (distance > PGM_DCAP; slots 7, 6, 5), served from the cell storage by the far
+//                    helper (the count of bits 0-3 then covers the slots before them)
+//          bits 20-24: number of OVERFLOW entries (on-chip entries beyond the slots of the summary, at most PGM_OV_ENT), kept in
+//                    record (bits 25-30) of the job's overflow table (PgmJob::ov2, copied to LDS by the far helpers)
 //   fd_k   (node - predecessor) of far edge k, 0 if absent;   fc_k its cost, +inf if absent
+// In a MODE 2 job the far entries of the ROWS are not taken from here but from the CSR PgmJob::fp1 / fe1 (any number per
+// row; an entry farther than PGM_DCAP or reaching above the band's virtual lanes is REMOTE: served from the cell storage).
 // The column ring of a sweep keeps {q0, q1, q3} (MODE 0 / 1: 3 float4 per column) or all five (MODE 2).
 #define PGM_NF_COUNT 15u
 #define PGM_NF_GENERIC 16u
 #define PGM_NF_KILL 32u
+#define PGM_NF_NLONG(f) (((f) >> 16) & 3u)
+#define PGM_NF_NOV(f) (((f) >> 20) & 31u)
+#define PGM_NF_OVI(f) (((f) >> 25) & 63u)
+#define PGM_OV_ENT 16      /* overflow entries per record */
+#define PGM_OV_REC 48      /* records per job (6 KB of LDS) */
+#define PGM_NLONG 3        /* long entries per column */
 struct PgmNode2 {
     float cc, c2, c3;
     uint32_t flags;
@@ -80,6 +95,8 @@ struct PgmJob {
     uint32_t hD, hDX;      // depth (steps, power of two) of the W / Y history and of the X history of a sweeping wavefront
     uint32_t slot_bytes;   // LDS bytes one sweeping wavefront needs for this job (history + column rings)
     uint32_t nslots;       // bands of this job one worker sweeps at a time = min(4, PGM_POOL / slot_bytes)
+    uint32_t long1, long2; // mode2 only: graph 1 has REMOTE row entries / graph 2 has LONG column entries (served from the cell
+                           // storage by the far helpers: farther than PGM_DCAP, or reaching above the band's virtual lanes)
     pgm_scores sc;
 
     // inputs as uploaded
@@ -90,6 +107,11 @@ struct PgmJob {
     const int32_t *xp1, *xp2;        // CSR ptr of the remaining ("extra") predecessors, n+1 entries
     const uint32_t *xc1, *xc2;       // extra predecessor node
     const float *xv1, *xv2;          // extra predecessor cost (repeat edges already evaluated)
+    // mode2: far entries of the ROWS as a CSR (any number per row): .x = distance | remote << 31, .y = cost bits
+    const int32_t *fp1;
+    const uint2 *fe1;
+    const uint2 *ov2;                // mode2: overflow table of the columns, nov2 records of PGM_OV_ENT {distance, cost bits}
+    uint32_t nov2, ov_off;           // records in use; offset of the table's copy inside a sweep's LDS slot
     // full predecessor lists in PredIterator order (regular ascending, then repeats) for the traceback
     const int32_t *pp1, *pp2;
     const uint32_t *pc1, *pc2;

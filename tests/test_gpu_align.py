@@ -33,6 +33,10 @@ FAMILIES = [
     dict(skip_frac=0.95, skip_max=9, drop_chain_frac=0.0),    # dense extras: more far edges per node than the history serves (generic path)
     dict(skip_frac=0.1, skip_span=70, repeat_frac=0.03, repeat_span=90),   # far edges: beyond the LDS history and the traceback tile
     dict(skip_frac=0.25, skip_span=27, skip_max=2),           # distances up to the on-chip limit: deepest history (64 steps), virtual lanes
+    # heavy-tailed graphs (MODE 2 with the long / remote entries of the far helpers):
+    dict(skip_frac=0.3, skip_span=150, skip_max=5),           # several long edges per node: long slots 7, 6, 5, remote rows, > 3 long: generic
+    dict(skip_frac=0.5, skip_span=27, skip_max=14),           # 9-14 on-chip entries per node: overflow table (and its 48-record limit), row CSR
+    dict(skip_frac=0.4, skip_span=60, skip_max=10, repeat_frac=0.05, repeat_span=120),   # everything mixed
 ]
 
 
@@ -43,6 +47,8 @@ def test_random_jobs_bit_exact(ctx, kw, dim):
     sizes = [(2, 2), (3, 2), (2, 5), (3, 3), (7, 4), (40, 33), (64, 64), (65, 66), (66, 65), (130, 97), (200, 310), (517, 129)]
     if dim == 61:   # the 61-state alphabet (codons): fewer sizes, same families incl. skip and repeat edges
         sizes = [(3, 2), (7, 4), (65, 66), (130, 97), (200, 310)]
+    if kw.get("skip_span", 0) >= 60 or kw.get("skip_max", 0) >= 10:   # several bands with remote rows and long columns in flight
+        sizes = sizes + [(700, 650)]
     js = [J.random_job(1000 + i, n1, n2, dim=dim, **kw) for i, (n1, n2) in enumerate(sizes)]
     b = J.Batch(ctx, js)
     b.run()

@@ -1,10 +1,13 @@
 #!/bin/bash
-# A/B of two builds of libpgm_hip.so on the same GPU box: tools/ab_bench.sh  (expects lib/libpgm_hip_A.so and _B.so)
+# A/B of several builds of libpgm_hip.so on the same GPU box: tools/ab_bench.sh  (expects lib/libpgm_hip_<name>.so files)
 cd "$(dirname "$0")/.."
+cp prographmsa_amd/lib/libpgm_hip.so /tmp/libpgm_hip_keep.so
 for round in 1 2; do
-for v in A B; do
-  cp prographmsa_amd/lib/libpgm_hip_$v.so prographmsa_amd/lib/libpgm_hip.so
-  python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+for f in prographmsa_amd/lib/libpgm_hip_*.so; do
+  v=$(basename $f .so); v=${v#libpgm_hip_}
+  cp $f prographmsa_amd/lib/libpgm_hip.so
+  python bench.py --no-cpu-baseline --no-extra 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['roofline']['ms'])"
 done
 done
+cp /tmp/libpgm_hip_keep.so prographmsa_amd/lib/libpgm_hip.so

@@ -8,9 +8,13 @@ tmp = tempfile.mkdtemp()
 trace = os.path.join(tmp, "trace.bin")
 import prographmsa_amd as pg
 from prographmsa_amd import jobs as J
-fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(gen.gen(256, 1000, 3)))
+cfg = os.environ.get("PROBE_CFG", "c3")   # c3: headline batch; c4 / c5: the heavy-tailed configs
+fam, flags = {"c3": (lambda: gen.gen(256, 1000, 3), ["--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree")]),
+              "c4": (lambda: gen.gen_codon(128, 1000, 4), ["--codon", "--fasta", "-t", os.path.join(ROOT, "tests/golden/c4.tree")]),
+              "c5": (lambda: gen.gen(1024, 600, 6), ["--fasta", "-t", os.path.join(ROOT, "tests/golden/c5.tree")])}[cfg]
+fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam()))
 dump = os.path.join(tmp, "jobs.bin")
-subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree"), "--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
+subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
 jobs = J.load_jobs(dump)
 os.environ["PGM_FILL_TRACE"] = trace
 for kv in os.environ.get("PROBE_ENV", "").split(","):   # experiment knobs that must not reach the product run above
