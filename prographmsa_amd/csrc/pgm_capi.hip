@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <queue>
 #include <cstdlib>
 #include <cstring>
@@ -114,6 +115,10 @@ int pgm_device_count(void) {
     return n;
 }
 
+// (launched once per context: the device code of the library is loaded when the context is created, not in the middle of
+// the first batch)
+__global__ void pgm_warm_kernel() {}
+
 int pgm_ctx_create(int device, pgm_ctx **out) {
     if (!out) return fail(PGM_ERR_INVALID, "null out");
     *out = nullptr;
@@ -125,6 +130,9 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     c->device = device;
     HIPCHK(hipGetDeviceProperties(&c->prop, device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
     *out = c;
     return PGM_OK;
 }
@@ -822,11 +830,19 @@ uint64_t pgm_align_batch_cells(const pgm_align_batch *b) { return b ? b->cells :
 int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) {
     pgm_align_batch *b = nullptr;
+    const bool prof = getenv("PGM_HOST_PROFILE") != nullptr;   // tools: where the time of one call goes
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = pgm_align_batch_create(ctx, njobs, g1, g2, model, scores, &b);
     if (rc != PGM_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     rc = pgm_align_batch_run(ctx, b);
     if (rc == PGM_OK) rc = pgm_align_batch_fetch(ctx, b, out);
+    const auto t2 = std::chrono::steady_clock::now();
     pgm_align_batch_destroy(ctx, b);
+    if (prof)
+        fprintf(stderr, "  pgm_align_graphs_batch: %u jobs, create (flatten, allocate, upload, work list) %.2f ms, run + fetch %.2f ms, destroy %.2f ms\n", njobs,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
     return rc;
 }
 
