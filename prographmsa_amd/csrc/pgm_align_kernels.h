@@ -357,6 +357,9 @@ __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, ui
     return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
 }
 
+#ifndef PGM_POLL_PREFETCH
+#define PGM_POLL_PREFETCH 1
+#endif
 #define PGM_TB_T 32        // tile edge (rows and columns)
 #define PGM_TB_BAND 6      // successor links are built for the diagonals within this distance of the walker's (half of it for chain-only jobs)
 #define PGM_TB_LK 4        // an M-state link is precomputed for cells whose two nodes have at most this many predecessors each
@@ -387,18 +390,20 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
     const PgmPred P1 = {J.pp1, J.pc1, J.pv1, J.pu1};
     const PgmPred P2 = {J.pp2, J.pc2, J.pv2, J.pu2};
 
-    // ---- tile staging, all threads (nthreads == 256: 4 cells and 2 predecessor entries each).  All loads of a thread
+    // ---- tile staging, all threads (nthreads == 512: 2 cells and 1 predecessor entry each).  All loads of a thread
     // are issued before the first LDS store (clamped, always valid addresses instead of branches), so a tile costs two
     // memory round trips (row pointers -> entries), not one per element. -------------------------------------------
     const bool loader = tid >= 64;   // wavefronts 1..: they only serve the walker (wavefront 0)
     auto stage = [&]() {
         const uint32_t ty0 = T.ty0, tx0 = T.tx0;
-        constexpr int NC = (int)(TT * TT) / 256, NP = (int)(2 * TT * PGM_TB_PK) / 256;
+        constexpr uint32_t NT = 64u * PGM_WAVES;
+        constexpr int NC = (int)((TT * TT) / NT), NP = (int)((2 * TT * PGM_TB_PK) / NT);
+        static_assert(NC * NT == TT * TT && NP * NT == 2 * TT * PGM_TB_PK, "tile staging: whole rounds of the workgroup");
         float4 cv[NC];
         float sv[NC];
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const uint32_t i = (uint32_t)tid + 256u * u;
+            const uint32_t i = (uint32_t)tid + NT * u;
             const uint32_t yy = min(ty0 + i / TT, n1 - 2), xx = min(tx0 + i % TT, n2 - 2);
             cv[u] = J.cells[pgm_cell_index(J, yy, xx)];
             sv[u] = pgm_emission_at(J, yy, xx);
@@ -409,7 +414,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         float ev[NP];
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const uint32_t i = (uint32_t)tid + NT * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
             const bool row = slot < TT;
             const uint32_t v = min(row ? ty0 + slot : tx0 + (slot - TT), (row ? n1 : n2) - 1);
             const PgmTbNode *r = (row ? J.tb1 : J.tb2) + v;
@@ -417,14 +422,14 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         }
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
-            const uint32_t i = (uint32_t)tid + 256u * u;
+            const uint32_t i = (uint32_t)tid + NT * u;
             T.cell[i] = cv[u];
             T.S[i] = sv[u];
         }
-        for (uint32_t i = (uint32_t)tid; i < 3u * TT * TT / 2u; i += 256u) ((uint32_t *)T.succ)[i] = 0u;   // no links yet
+        for (uint32_t i = (uint32_t)tid; i < 3u * TT * TT / 2u; i += NT) ((uint32_t *)T.succ)[i] = 0u;   // no links yet
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            const uint32_t i = (uint32_t)tid + 256u * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
+            const uint32_t i = (uint32_t)tid + NT * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
             const bool row = slot < TT;
             const bool inr = (row ? ty0 + slot : tx0 + (slot - TT)) < (row ? n1 : n2);
             if (k == 0) T.p_cnt[slot] = inr ? cnt[u] : 0xFFFFFFFFu;
@@ -846,7 +851,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // wavefront on its own (no helper wavefronts, no barrier inside a sweep).  Lane l owns row y = 64 b + l and at step t
 // computes column x = t - l: the cells of one step are independent of each other, every predecessor cell was produced
 // by a lower or the same lane at an earlier step.  An item of the work list is up to four consecutive bands of one
-// job, one per wavefront of the worker (256-thread workgroup) that takes it; all bands of all jobs of the batch sit in
+// job, one per wavefront of the worker (512-thread workgroup) that takes it; all bands of all jobs of the batch sit in
 // one list ordered by the host (longest remaining path first), a persistent grid of workers takes them through an
 // atomic ticket.  Band b of a job is always listed after band b-1, so the wavefront it waits for is already running.
 //
@@ -925,12 +930,11 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
     const float4 *ni2q = (const float4 *)J.ni2;
     const uint32_t lb = (uint32_t)(VL + lane);
-    const float *resA = (const float *)(slot + J.aux_off + PGM_AUX_RES), *resB = resA + 768, *resC = resA + 1536;
-    const bool use_far = has_far && !(dbg_flags & 16u);
-    int seenA = (dbg_flags & 32u) ? 0x7fffffff : 0, seenB = use_far ? 0 : 0x7fffffff, seenC = seenB;   // HELPED: steps whose terms the helpers have published
-    const bool skipB = (dbg_flags & 256u) != 0, skipC = (dbg_flags & 512u) != 0;   // experiments: do not wait for that helper (wrong results)
-    if (skipB) seenB = 0x7fffffff;
-    if (skipC) seenC = 0x7fffffff;
+    float *res = (float *)(slot + J.aux_off + PGM_AUX_RES);
+    // HELPED: the helper wavefronts whose terms this sweep waits for (bit h = wavefront h of the worker): 1, 2 the near terms,
+    // 3, 4 the far edges of the columns, 5-7 the far edges of the rows (experiment switches: 32 without the former, 16 the latter)
+    const uint32_t hmask = HELPED ? ((((dbg_flags & 32u) ? 0u : 0x06u) | ((has_far && !(dbg_flags & 16u)) ? 0xf8u : 0u)) & ~(dbg_flags >> 16)) : 0u;   // (bits 17-23 of the switches: do not wait for that wavefront)
+    int seen_min = hmask ? 0 : 0x7fffffff;   // steps whose terms every helper has published
 
     for (uint32_t i = (uint32_t)lane; i < D * HS; i += 64u) { hW[i] = PGM_NEG_INF; hY[i] = PGM_NEG_INF; }
     for (uint32_t i = (uint32_t)lane; i < DX * 64u; i += 64u) hX[i] = PGM_NEG_INF;
@@ -948,7 +952,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
         pfq = v;
     };
     auto store_ring_block = [&](uint32_t c0) {
-        if (lane < RS * BL) ring3[((c0 + (uint32_t)rq_col) & (uint32_t)(NR - 1)) * (uint32_t)RS + (uint32_t)rq_part] = pfq;
+        if (lane < RS * BL) ring3[(uint32_t)rq_part * (uint32_t)NR + ((c0 + (uint32_t)rq_col) & (uint32_t)(NR - 1))] = pfq;
     };
     auto load_s_block = [&](uint32_t s0) {
         const uint32_t tb = min(s0 / BL, nblk - 1u);   // (a block beyond the sweep is never consumed: any valid address will do)
@@ -1019,6 +1023,8 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     load_rep_block(BL);
     poll_issue();
     if (HELPED) {   // history initialised, first blocks staged: the helpers may start (sw[0] = last recorded step + 2)
+        for (int i = lane; i < 4 * 192; i += 64) res[i] = PGM_NEG_INF;
+        if (lane >= 1 && lane < PGM_WAVES && !(hmask & (1u << lane))) sw[lane] = 0x7fffffff;   // wavefronts that publish nothing for this item
         asm volatile("" ::: "memory");
         __hip_atomic_store(sw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -1030,7 +1036,9 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     float u1Y = PGM_NEG_INF, u2Y = PGM_NEG_INF, u3Y = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF;
     // LDS operands of a step are read one step ahead: the column summary and lane 0's upper neighbours (virtual lanes of the
     // history; all lanes read the same word, only lane 0 keeps it: `old` operand of the DPP shift)
-    float4 cn_n = ring3[(((uint32_t)(-lane)) & (uint32_t)(NR - 1)) * (uint32_t)RS];
+    typedef int pgm_v4i __attribute__((ext_vector_type(4)));
+    pgm_v4i hw_a = {0, 0, 0, 0}, hw_b = {0, 0, 0, 0};   // HELPED: the helpers' counters as read a step ago
+    float4 cn_n = ring3[((uint32_t)(-lane)) & (uint32_t)(NR - 1)];
     float inW1 = hW[(0xFFFFFFFFu & Dm) * HS + VL - 1], inY1 = hY[(0xFFFFFFFFu & Dm) * HS + VL - 1];
     float inW2 = hW[(0xFFFFFFFEu & Dm) * HS + VL - 2], inY2 = hY[(0xFFFFFFFEu & Dm) * HS + VL - 2];
     float inW3 = hW[(0xFFFFFFFDu & Dm) * HS + VL - 3], inY3 = hY[(0xFFFFFFFDu & Dm) * HS + VL - 3];
@@ -1043,44 +1051,57 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             // VALU select stalls the in-order wavefront twice): ncol_row = ncol for a valid row, 0 for the rows below the matrix
             const bool active = (uint32_t)xs < ncol_row;
             const uint32_t x = (uint32_t)xs;
-            const uint32_t rslot = (x & (uint32_t)(NR - 1)) * (uint32_t)RS;
+            const uint32_t rslot = x & (uint32_t)(NR - 1);   // column summaries: part-major, part k of column c at ring3[k * NR + (c & (NR - 1))]
             const float4 cn = cn_n;
             const float iW1 = inW1, iY1 = inY1, iW2 = inW2, iY2 = inY2, iW3 = inW3, iY3 = inY3;
             if (HELPED && !(dbg_flags & 2u)) {
-                // the helper wavefronts run ahead: normally their terms of this step are already published (no LDS access here)
+                // The helper wavefronts run ahead.  Their seven counters (words of wavefronts that do not take part were set to
+                // "far ahead" in the prologue) are read with the look-ahead operands of the PREVIOUS step — two 128-bit reads of the
+                // same words by every lane, minimum on the vector unit — so normally this step only compares; it reads them
+                // again (and waits) only if the helpers really are behind.
                 const int want = (int)t + 1;
-                if (__builtin_expect(seenA < want || seenB < want || seenC < want, 0)) {
+#if PGM_POLL_PREFETCH
+                {
+                    int m = min(min(hw_a.y, hw_a.z), min(hw_a.w, hw_b.x));
+                    m = min(m, min(min(hw_b.y, hw_b.z), hw_b.w));
+                    seen_min = max(seen_min, __builtin_amdgcn_readfirstlane(m));
+                }
+#endif
+                if (__builtin_expect(seen_min < want, 0)) {
                     uint32_t spins = 0;
                     const unsigned long long h0 = wait_acc ? __builtin_amdgcn_s_memrealtime() : 0ull;
                     for (;;) {
-                        if (!(dbg_flags & 32u)) seenA = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (use_far) {
-                            if (!skipB) seenB = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            if (!skipC) seenC = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        }
-                        if (seenA >= want && seenB >= want && seenC >= want) break;
+                        const pgm_v4i wa = *(const __attribute__((address_space(3))) pgm_v4i *)sw, wb = *(const __attribute__((address_space(3))) pgm_v4i *)(sw + 4);
+                        int m = min(min(wa.y, wa.z), min(wa.w, wb.x));
+                        m = min(m, min(min(wb.y, wb.z), wb.w));
+                        seen_min = __builtin_amdgcn_readfirstlane(m);
+                        if (seen_min >= want) break;
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1u << 22)) { __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); aborted = true; break; }
                     }
                     if (wait_acc) wait_acc[1] += __builtin_amdgcn_s_memrealtime() - h0;
                 }
                 asm volatile("" ::: "memory");
+#if PGM_POLL_PREFETCH
+                hw_a = *(const __attribute__((address_space(3))) pgm_v4i *)sw; hw_b = *(const __attribute__((address_space(3))) pgm_v4i *)(sw + 4);   // for step t + 1
+#endif
             }
             if (!(dbg_flags & 64u)) {   // operands of step t + 1 (their virtual-lane entries and column summaries were staged at least a block ago)
-                cn_n = ring3[((x + 1u) & (uint32_t)(NR - 1)) * (uint32_t)RS];
+                cn_n = ring3[(x + 1u) & (uint32_t)(NR - 1)];
                 const uint32_t tm0 = (t & Dm) * HS, tm1 = ((t - 1u) & Dm) * HS, tm2 = ((t - 2u) & Dm) * HS;
                 inW1 = hW[tm0 + VL - 1]; inY1 = hY[tm0 + VL - 1];
                 if (EXTRAS) { inW2 = hW[tm1 + VL - 2]; inY2 = hY[tm1 + VL - 2]; }
                 if (NEAR) { inW3 = hW[tm2 + VL - 3]; inY3 = hY[tm2 + VL - 3]; }
             }
-            // partial maxima of the helpers for this step: issued with the other LDS operands, merged after the chain terms
-            float rAM = PGM_NEG_INF, rAX = PGM_NEG_INF, rAY = PGM_NEG_INF, rBM = PGM_NEG_INF, rBX = PGM_NEG_INF, rCM = PGM_NEG_INF, rCY = PGM_NEG_INF;
+            // maxima over the helpers' terms of this step: read with the other LDS operands, merged after the chain terms; the
+            // words are reset for step t + 4 (no helper writes that step before this one is recorded: far_slack <= 4)
+            float rM = PGM_NEG_INF, rX = PGM_NEG_INF, rY = PGM_NEG_INF;
             if (HELPED && !(dbg_flags & 2u)) {
                 const uint32_t ro = (t & 3u) * 192u + (uint32_t)lane;
-                if (!(dbg_flags & 32u)) { rAM = resA[ro]; rAX = resA[ro + 64]; rAY = resA[ro + 128]; }
-                if (use_far) { rBM = resB[ro]; rBX = resB[ro + 64]; rCM = resC[ro]; rCY = resC[ro + 128]; }
+                rM = res[ro]; rX = res[ro + 64]; rY = res[ro + 128];
+                res[ro] = PGM_NEG_INF; res[ro + 64] = PGM_NEG_INF; res[ro + 128] = PGM_NEG_INF;
             }
-            const float ccx = cn.x, c2x = EXTRAS ? cn.y : INFINITY, c3x = NEAR ? cn.z : INFINITY;
+            const float ccx = cn.x, c2x = EXTRAS ? cn.y : INFINITY, c3x = EXTRAS ? cn.z : INFINITY;
             const uint32_t fx = __float_as_uint(cn.w);
             const bool genx = EXTRAS && active && (fx & PGM_NF_GENERIC) != 0;
             const bool xkill = (fx & PGM_NF_KILL) != 0;
@@ -1106,16 +1127,17 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             float Xv = xterm(ox[sm1], ow[sm1], ccx);
             float Yv = yterm(u1Y, u1W[s0], ccy);
             if (HELPED) {
-                // the terms that read step t - 2 are evaluated here too (X from column x-2, Y from row y-2: own registers); every
-                // other term of this step only needs the history up to step t - 3 and comes from the helper wavefronts: the other
-                // near terms (A), the far edges of the columns (B), the far edges of the rows (C)
-                Xv = fmaxf(Xv, xterm(ox[sm2], ow[sm2], c2x));
+                // the terms that read steps t - 2 and t - 3 from this wavefront's own register windows are evaluated here too (X from
+                // columns x-2 and x-3, Y from row y-2, the M pairs (y-1, x-2) and (y-2, x-1)); every other term of this step comes from
+                // the helper wavefronts: Y from row y-3 (history of step t - 3), the other near pairs and the far edges (step t - 4 and older)
+                Xv = fmaxf(Xv, fmaxf(xterm(ox[sm2], ow[sm2], c2x), xterm(ox[sm3], ow[sm3], c3x)));
                 Yv = fmaxf(Yv, yterm(u2Y, u2W[s0], c2y));
+                Mv = fmaxf(Mv, fmaxf(mterm(u1W[sm2], ccy, c2x), mterm(u2W[sm1], c2y, ccx)));
             }
             if (HELPED) {
-                Mv = fmaxf(fmaxf(Mv, rAM), fmaxf(rBM, rCM));
-                Xv = fmaxf(Xv, fmaxf(rAX, rBX));
-                Yv = fmaxf(Yv, fmaxf(rAY, rCY));
+                Mv = fmaxf(Mv, rM);
+                Xv = fmaxf(Xv, rX);
+                Yv = fmaxf(Yv, rY);
             }
             if (NEAR) {
                 Mv = fmaxf(Mv, fmaxf(mterm(u1W[sm2], ccy, c2x), mterm(u1W[sm3], ccy, c3x)));
@@ -1126,7 +1148,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 // ---- far edges: LDS history ----
                 const uint32_t nfx = fx & PGM_NF_COUNT;
                 if (__builtin_expect(nfyw != 0 || __builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull, 0)) {
-                    const float4 f1 = ring3[rslot + 1u], f2 = ring3[rslot + 2u];
+                    const float4 f1 = ring3[rslot + (uint32_t)NR], f2 = ring3[rslot + 2u * (uint32_t)NR];
                     const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w)};
                     const float fcx[KF] = {f2.x, f2.y, f2.z, f2.w};
                     const int nfxw = pgm_wave_max8(nfx);
@@ -1243,21 +1265,28 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     if (lane == 0 && !stall) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Helper wavefronts of a MODE 2 sweep (PgmJob::mode2).  The sweeping wavefront keeps the terms that read steps t - 1 and
-// t - 2 (chain M, X, Y; X from column x-2, Y from row y-2).  Every other term of step t reads the history no later than
-// step t - 3, so three helper wavefronts evaluate them up to two steps ahead of the sweep (their latency is off its
-// critical path as long as their throughput keeps up), each leaving its partial maxima per lane in its own ring res[t & 3]:
-//   GROUP 0  the other near terms: eight M pairs (rows y-1..y-3 x columns x-1..x-3 without the chain pair), X from column
-//            x-3, Y from row y-3; one row per lane like the sweep
-//   GROUP 1  the far edges of the COLUMNS, one row per lane (a column's far edges pass down the lanes one step at a time):
-//            X term, M terms with the three near rows; loop to the wavefront's largest count
-//   GROUP 2  the far edges of the ROWS, one (row, far edge) ENTRY per lane — a band has a handful of them, a lane per row
-//            would loop to the largest count per row for all 64 rows: Y term, M terms with the three near columns and with
-//            the far edges of the entry's current column; merged per owner row with LDS float-max atomics (exact, order free)
+// Helper wavefronts of a MODE 2 sweep (PgmJob::mode2): wavefronts 1-7 of the worker.  The sweeping wavefront keeps the terms
+// it can evaluate from its own register windows (chain M, X, Y; X from columns x-2, x-3, Y from row y-2, the M pairs
+// (y-1, x-2) and (y-2, x-1)).  Every other term of step t reads the history no later than step t - 3 (all but one no
+// later than t - 4), so the helpers evaluate them up to a few steps ahead of the sweep (their latency is
+// off its critical path as long as their throughput keeps up) and fold them per lane into ONE set of maxima res[t & 3]
+// {M, X, Y} with LDS float-max atomics (exact, order free; the sweep resets the words after reading them):
+//   GROUP 0  (wavefronts 1, 2) the near terms the sweep does not hold in registers, one row per lane like the sweep: Y from
+//            row y-3 (part 0: the only helper term that reads step t - 3, slack 3), the six M pairs of rows y-1..y-3 x
+//            columns x-1..x-3 that read step t - 4 or older (part 1, slack 4)
+//   GROUP 1  (wavefronts 3, 4) the far edges of the COLUMNS, one row per lane (a column's far edges pass down the lanes one
+//            step at a time): X term, M terms with the three near rows.  On-chip entries (summary slots and the overflow
+//            table): every other one each; in a job with long column entries wavefront 3 takes all on-chip entries and
+//            wavefront 4 (LONG) the long ones
+//   GROUP 2  (wavefronts 5-7) the far edges of the ROWS, one (row, far edge) ENTRY per lane — a band has a handful of them,
+//            a lane per row would loop to the largest count per row for all 64 rows: Y term, M terms with the three near
+//            columns and with the far edges of the entry's current column.  Part k takes the passes k, k + 3, k + 6 of the
+//            band's entry list.
 // (groups 1 and 2 may run up to far_slack steps ahead of what is recorded.)  The wavefronts only meet through LDS words:
-// sw[0] = last step the sweeping wavefront has recorded + 2 (1 = its prologue is done), sw[1 + GROUP] = number of steps
-// whose terms are published.
-// LONG = true (PgmJob::long1 / long2): some entries are not in the LDS history — up to PGM_NLONG column entries farther than
+// sw[0] = last step the sweeping wavefront has recorded + 2 (1 = its prologue is done), sw[h] = number of steps whose terms
+// helper wavefront h has published, sw[8] = the band's row entry list is built (by part 0 of group 2).
+//
+// LONG = true (PgmJob::long1 / long2): entries that are not in the LDS history — up to PGM_NLONG column entries farther than
 // PGM_DCAP (slots 7, 6, 5 of the column summary) or REMOTE row entries (farther than PGM_DCAP, or above the virtual lanes).
 // Their sources are read from the cell storage: they were stored at least 16 steps before the last recorded step, i.e.
 // before the sweeping wavefront's last counted wait (same band), or are covered by the progress of the band above.  The
@@ -1267,12 +1296,15 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 // column itself, so a lane only loads the cell of its OWN row; W of the three rows above comes from the lanes above, one
 // step later each (the same systolic window as in the sweep; lanes 1-3 load lane 0's three rows of the band above).
 // Columns with more on-chip entries than the summary holds keep the rest in an overflow table (LDS copy, any helper).
-template <int GROUP, bool LONG>
-__device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic, const int slack_extra = 0) {
-    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5, PF = PGM_PF, NL = PGM_NLONG;
+template <int GROUP, bool LONG, bool MASK = false>   // MASK: the column summaries of this job may hold long entries in their last slots
+__device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic,
+                                                 const int hidx, const uint32_t part, const uint32_t nparts, const bool idle = false) {
+    constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5, PF = PGM_PF, NL = PGM_NLONG, KQ = 3;
     static_assert(PF == 4 && BL == 8, "FIFO slots are indexed with i & 3");
     static_assert(PGM_DCAP + 1 - (4 + PF) >= 16 + 3, "a long source must be stored before the sweep's last counted wait");
+    static_assert(KQ * PGM_CPARTS >= KF, "every pass of the entry list has an owner");
     typedef __attribute__((address_space(3))) int pgm_lds_int;
+    typedef __attribute__((address_space(3))) float pgm_lds_float;
     typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
     typedef uint32_t pgm_v2u __attribute__((ext_vector_type(2)));
     pgm_lds_int *sw = (pgm_lds_int *)sw_generic;
@@ -1282,12 +1314,12 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     const float *hW = (const float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
     const float4 *ring3 = (const float4 *)(hX + DX * 64u);
     uint8_t *aux = slot + J.aux_off;
-    float *res = (float *)(aux + PGM_AUX_RES) + GROUP * 768, *sblk = (float *)(aux + PGM_AUX_SBLK);
+    float *res = (float *)(aux + PGM_AUX_RES), *sblk = (float *)(aux + PGM_AUX_SBLK) + part * 512u;
     uint2 *elist = (uint2 *)(aux + PGM_AUX_EL);
     int *ecnt = (int *)(aux + PGM_AUX_CNT);
     uint2 *ovtab = (uint2 *)(slot + J.ov_off);
     const bool has_ov = GROUP != 0 && J.nov2 != 0;
-    const int slack = (GROUP == 0 ? 3 : (int)J.far_slack) + slack_extra;   // (slack_extra: timing experiments only, wrong results)
+    const int slack = GROUP == 0 ? (part == 0u ? 3 : 4) : (int)J.far_slack;
     const uint32_t y = 64u * b + (uint32_t)lane;
     const bool rowvalid = y + 1 < n1, has_prev = b > 0;
     const uint32_t yc = rowvalid ? y : 0u;
@@ -1301,6 +1333,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     const uint32_t ncol_row = rowvalid ? ncol : 0u;
     const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
     const uint32_t lb = (uint32_t)(VL + lane);
+    auto fold = [&](float *p, float v) { __builtin_amdgcn_ds_fmaxf((pgm_lds_float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false); };
     // cell (r, c) of the job = byte offset row_off(r) + c * 1024 into the job's cell storage (32-bit: the host only
     // marks entries long / remote when the job's storage is smaller than 4 GiB)
     const __amdgpu_buffer_rsrc_t job_rsrc = pgm_band_rsrc(J.cells, LONG ? J.nb * tsteps * 1024u : 16u);
@@ -1309,55 +1342,66 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
         const pgm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(job_rsrc, off + 8u, 0, 16);
         return __uint_as_float(v.x);
     };
-    if (has_ov) {   // (both far helpers copy the table: same values to the same words, no hand-shake needed)
+    if (has_ov) {   // (every far helper copies the table: same values to the same words, no hand-shake needed)
         for (uint32_t i = (uint32_t)lane; i < J.nov2 * (uint32_t)PGM_OV_ENT; i += 64u) ovtab[i] = make_uint2(pgm_gld(&J.ov2[i].x), pgm_gld(&J.ov2[i].y));
     }
-    // GROUP 2: entry list of the band, remote entries first (order irrelevant otherwise).  LDS operations of one wavefront
-    // execute in order.
+    // GROUP 2: entry list of the band, remote entries first (order irrelevant otherwise), built by part 0.  LDS operations of
+    // one wavefront execute in order.
     int ne = 0;
-    uint32_t e_o[KF], e_dy[KF];
-    float e_cy[KF];
-    bool e_ok[KF], e_rem[2] = {false, false};
-    uint32_t e_off[2] = {0u, 0u};
+    uint32_t e_o[KQ], e_dy[KQ];
+    float e_cy[KQ];
+    bool e_ok[KQ], e_rem = false;
+    uint32_t e_off = 0u;
     if (GROUP == 2) {
-        __hip_atomic_store(ecnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(ecnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int32_t f0 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc) : 0, f1 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc + 1) : 0;
-        uint32_t nrem = 0, nloc = 0;
-        for (int32_t e = f0; e < f1; ++e) { if (pgm_gld(&J.fe1[e].x) >> 31) ++nrem; else ++nloc; }
-        uint32_t baseR = 0, baseL = 0;
-        if (nrem) baseR = (uint32_t)__hip_atomic_fetch_add(ecnt, (int)nrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (nloc) baseL = (uint32_t)__hip_atomic_fetch_add(ecnt + 1, (int)nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (part == 0u) {
+            __hip_atomic_store(ecnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ecnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int32_t f0 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc) : 0, f1 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc + 1) : 0;
+            uint32_t nrem = 0, nloc = 0;
+            for (int32_t e = f0; e < f1; ++e) { if (pgm_gld(&J.fe1[e].x) >> 31) ++nrem; else ++nloc; }
+            uint32_t baseR = 0, baseL = 0;
+            if (nrem) baseR = (uint32_t)__hip_atomic_fetch_add(ecnt, (int)nrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (nloc) baseL = (uint32_t)__hip_atomic_fetch_add(ecnt + 1, (int)nloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            baseL += (uint32_t)totR;
+            for (int32_t e = f0; e < f1; ++e) {
+                const uint32_t dx = pgm_gld(&J.fe1[e].x), cb = pgm_gld(&J.fe1[e].y);
+                const uint32_t pos = (dx >> 31) ? baseR++ : baseL++;
+                if (pos < 512u) elist[pos] = make_uint2((uint32_t)lane | ((dx & 0x7fffffu) << 8) | (dx & 0x80000000u), cb);
+            }
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(sw + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+        }
         const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const int totL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        baseL += (uint32_t)totR;
-        for (int32_t e = f0; e < f1; ++e) {
-            const uint32_t dx = pgm_gld(&J.fe1[e].x), cb = pgm_gld(&J.fe1[e].y);
-            const uint32_t pos = (dx >> 31) ? baseR++ : baseL++;
-            if (pos < 512u) elist[pos] = make_uint2((uint32_t)lane | ((dx & 0x7fffffu) << 8) | (dx & 0x80000000u), cb);
-        }
         ne = min(totR + totL, 512);   // (the host keeps a band within 512 entries and PGM_REMOTE_MAX remote ones)
 #pragma unroll
-        for (int p = 0; p < KF; ++p) {
-            const int idx = p * 64 + lane;
-            e_ok[p] = idx < ne;
-            const uint2 a = e_ok[p] ? elist[idx] : make_uint2((uint32_t)lane | (1u << 8), __float_as_uint(INFINITY));
-            e_o[p] = a.x & 255u; e_dy[p] = (a.x >> 8) & 0x7fffffu; e_cy[p] = __uint_as_float(a.y);
-            if (LONG && p < 2) {
-                e_rem[p] = (a.x >> 31) != 0;
-                if (e_rem[p]) e_off[p] = row_off(64u * b + e_o[p] - e_dy[p]);
+        for (int q = 0; q < KQ; ++q) {
+            const int idx = (int)(part + nparts * (uint32_t)q) * 64 + lane;
+            e_ok[q] = idx < ne;
+            const uint2 a = e_ok[q] ? elist[idx] : make_uint2((uint32_t)lane | (1u << 8), __float_as_uint(INFINITY));
+            e_o[q] = a.x & 255u; e_dy[q] = (a.x >> 8) & 0x7fffffu; e_cy[q] = __uint_as_float(a.y);
+            if (LONG && q == 0) {
+                e_rem = (a.x >> 31) != 0;
+                if (e_rem) e_off = row_off(64u * b + e_o[q] - e_dy[q]);
             }
         }
     }
-    const int npass = (ne + 63) / 64;
-    // GROUP 2, LONG: {W, Y} of the source row of the remote entry of passes 0 and 1 at the columns x .. x + PF - 1 (FIFO) and W
-    // at x-1 .. x-3 (window)
-    float2 rf[2][PF];
-    float rw[2][4];
-    auto issue2 = [&](int p, int col, int slot_ix) {   // {W, Y} of the remote source of pass p at column col
-        const bool ok = e_rem[p] && (uint32_t)col < ncol;
-        const pgm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(job_rsrc, (ok ? e_off[p] + (uint32_t)col * 1024u : 0u) + 8u, 0, 16);
-        rf[p][slot_ix] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    if (GROUP == 2 && !LONG && (int)part * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
+        __hip_atomic_store(sw + hidx, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    // GROUP 2, LONG: {W, Y} of the source row of the remote entry of the part's first pass (passes 0 and 1 hold the remote
+    // entries) at the columns x .. x + PF - 1 (FIFO) and W at x-1 .. x-3 (window)
+    float2 rf[PF];
+    float rw[4];
+    auto issue2 = [&](int col, int slot_ix) {   // {W, Y} of the remote source at column col
+        const bool ok = e_rem && (uint32_t)col < ncol;
+        const pgm_v2u v = __builtin_amdgcn_raw_buffer_load_b64(job_rsrc, (ok ? e_off + (uint32_t)col * 1024u : 0u) + 8u, 0, 16);
+        rf[slot_ix] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     // GROUP 1, LONG: per long slot s, X and W of the lane's row at the source column of the long entry of the columns
     // x .. x + PF - 1 (FIFO), lane 0's three rows above in lanes 1-3 (FIFO), and the systolic window of the rows above
@@ -1367,10 +1411,10 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     const uint32_t aux_off = aux_ok ? row_off(64u * b - (uint32_t)lane) : 0u;
     auto issue1 = [&](int xq, int slot_ix) {           // sources of the long entries of column xq, if it has any
         const bool act = (uint32_t)xq < ncol_row;
-        const uint32_t rq = ((uint32_t)xq & (uint32_t)(NR - 1)) * (uint32_t)RS;
+        const uint32_t rq = (uint32_t)xq & (uint32_t)(NR - 1);
         const uint32_t nl = act ? PGM_NF_NLONG(__float_as_uint(ring3[rq].w)) : 0u;
         float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (__builtin_amdgcn_ballot_w64(nl != 0u) != 0ull) dq = ring3[rq + 2u];
+        if (__builtin_amdgcn_ballot_w64(nl != 0u) != 0ull) dq = ring3[rq + 2u * (uint32_t)NR];
 #pragma unroll
         for (int s = 0; s < NL; ++s) {
             const bool has = nl > (uint32_t)s;
@@ -1389,10 +1433,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     };
     if (LONG && GROUP == 2) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rw[p][k] = PGM_NEG_INF;
-        }
+        for (int k = 0; k < 4; ++k) rw[k] = PGM_NEG_INF;
     }
     if (LONG && GROUP == 1) {
 #pragma unroll
@@ -1415,7 +1456,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             if (GROUP == 1) issue1(s - lane, s);
-            else { issue2(0, s - (int)e_o[0], s); issue2(1, s - (int)e_o[1], s); }
+            else issue2(s - (int)e_o[0], s);
         }
     }
     for (uint32_t t0 = 0; t0 < tsteps; t0 += BL) {
@@ -1431,38 +1472,31 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
         for (int i = 0; i < BL; ++i) {
             const uint32_t t = t0 + (uint32_t)i;
             const int need = max(1, (int)t - slack + 2);
-            while (seen < need) {   // (a sleeping poll: a tight one would keep the CU's LDS pipeline and this SIMD's issue slots busy)
+            while (seen < need) {   // (a sleeping poll: a tight one would keep the CU's LDS pipeline and this SIMD's issue slots busy;
+                                    //  the far helpers have three steps of lead, the wavefront of the step t - 3 term has none to give away)
                 seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (seen < need) __builtin_amdgcn_s_sleep(1);
+                if (seen < need) { if (GROUP == 0) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }
             }
             asm volatile("" ::: "memory");
             const int xs = (int)t - lane;
-            const uint32_t rslot = (((uint32_t)xs) & (uint32_t)(NR - 1)) * (uint32_t)RS;
+            const uint32_t rslot = ((uint32_t)xs) & (uint32_t)(NR - 1);
             const float4 cn = ring3[rslot];
             float *rs = res + (t & 3u) * 192u;
             const int s0 = i & 3, sm1 = (i + 3) & 3, sm2 = (i + 2) & 3, sm3 = (i + 1) & 3;
-            if (GROUP == 0) {
+            if (idle) {   // (experiments: hand-shake only)
+            } else if (GROUP == 0) {
                 const float S = Sc[i];
-                const float gopen_y = (xs == 0) ? sg : gi;
-                const float cy[3] = {ccy, c2y, c3y}, cx[3] = {cn.x, cn.y, cn.z};
-                float w[3][3];
-#pragma unroll
-                for (int dy = 1; dy <= 3; ++dy)
-#pragma unroll
-                    for (int dx = 1; dx <= 3; ++dx)
-                        if (dy + dx > 2) w[dy - 1][dx - 1] = hW[((t - (uint32_t)(dy + dx)) & Dm) * HS + lb - (uint32_t)dy];
+                auto w_at = [&](int dy, int dx) { return hW[((t - (uint32_t)(dy + dx)) & Dm) * HS + lb - (uint32_t)dy]; };
+                auto mt = [&](float w, float cy, float cx) { return __fsub_rn(__fsub_rn(__fadd_rn(w, S), cy), cx); };
                 const uint32_t s3 = t - 3u;
-                const float X3 = hX[(s3 & DXm) * 64u + (uint32_t)lane], Wx3 = hW[(s3 & Dm) * HS + lb];
-                const float Y3 = hY[(s3 & Dm) * HS + lb - 3u], Wy3 = hW[(s3 & Dm) * HS + lb - 3u];
-                float Mn = PGM_NEG_INF;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
-                        if (dy + dx > 0) Mn = fmaxf(Mn, __fsub_rn(__fsub_rn(__fadd_rn(w[dy][dx], S), cy[dy]), cx[dx]));
-                rs[lane] = Mn;
-                rs[64 + lane] = __fsub_rn(fmaxf(__fadd_rn(X3, ge), __fadd_rn(Wx3, gopen_x)), cn.z);
-                rs[128 + lane] = __fsub_rn(fmaxf(__fadd_rn(Y3, ge), __fadd_rn(Wy3, gopen_y)), c3y);
+                if (part == 0u) {   // Y from row y-3: the only helper term that reads step t - 3 (this wavefront follows the sweep most closely)
+                    const float Y3 = hY[(s3 & Dm) * HS + lb - 3u], Wy3 = hW[(s3 & Dm) * HS + lb - 3u];
+                    const float gopen_y = (xs == 0) ? sg : gi;
+                    fold(rs + 128 + lane, __fsub_rn(fmaxf(__fadd_rn(Y3, ge), __fadd_rn(Wy3, gopen_y)), c3y));
+                } else {            // the six near pairs that read step t - 4 and older: (1,3) (2,2) (3,1) (2,3) (3,2) (3,3)
+                    const float w13 = w_at(1, 3), w22 = w_at(2, 2), w31 = w_at(3, 1), w23 = w_at(2, 3), w32 = w_at(3, 2), w33 = w_at(3, 3);
+                    fold(rs + lane, fmaxf(fmaxf(fmaxf(mt(w13, ccy, cn.z), mt(w22, c2y, cn.y)), fmaxf(mt(w31, c3y, cn.x), mt(w23, c2y, cn.z))), fmaxf(mt(w32, c3y, cn.y), mt(w33, c3y, cn.z))));
+                }
             } else if (GROUP == 1) {
                 const float S = Sc[i];
                 auto xterm = [&](float xp, float wp, float cx) { return __fsub_rn(fmaxf(__fadd_rn(xp, ge), __fadd_rn(wp, gopen_x)), cx); };
@@ -1476,38 +1510,40 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                     Xf = fmaxf(Xf, xterm(Xh, Wh, cj));
                     Mf = fmaxf(Mf, mterm3(W1, W2, W3, cj));
                 };
-                // ---- column entries, one row per lane ----
                 const uint32_t fxw = (uint32_t)xs < ncol_row ? __float_as_uint(cn.w) : 0u;
-                const uint32_t nfx = fxw & PGM_NF_COUNT;
                 float Mf = PGM_NEG_INF, Xf = PGM_NEG_INF;
-                if (__builtin_amdgcn_ballot_w64(nfx != 0u) != 0ull) {
-                    const int nfxw = pgm_wave_max8(nfx);
-                    const float4 f1 = ring3[rslot + 1u], f2 = ring3[rslot + 3u];
-                    float4 f1b = make_float4(0.f, 0.f, 0.f, 0.f), f2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-                    if (nfxw > 4) { f1b = ring3[rslot + 2u]; f2b = ring3[rslot + 4u]; }
-                    const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w),
-                                              __float_as_uint(f1b.x), __float_as_uint(f1b.y), __float_as_uint(f1b.z), __float_as_uint(f1b.w)};
-                    const float fcx[KF] = {f2.x, f2.y, f2.z, f2.w, f2b.x, f2b.y, f2b.z, f2b.w};
+                if (!LONG) {
+                    // ---- on-chip column entries, one row per lane; this wavefront's share: entries j = part, part + nparts, ... ----
+                    const uint32_t nfx = fxw & PGM_NF_COUNT;
+                    if (__builtin_amdgcn_ballot_w64(nfx > part) != 0ull) {
+                        const int nfxw = pgm_wave_max8(nfx);
+                        const float4 f1 = ring3[rslot + (uint32_t)NR], f2 = ring3[rslot + 3u * (uint32_t)NR];
+                        float4 f1b = make_float4(0.f, 0.f, 0.f, 0.f), f2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+                        if (nfxw > 4) { f1b = ring3[rslot + 2u * (uint32_t)NR]; f2b = ring3[rslot + 4u * (uint32_t)NR]; }
+                        const uint32_t fdx[KF] = {__float_as_uint(f1.x), __float_as_uint(f1.y), __float_as_uint(f1.z), __float_as_uint(f1.w),
+                                                  __float_as_uint(f1b.x), __float_as_uint(f1b.y), __float_as_uint(f1b.z), __float_as_uint(f1b.w)};
+                        const float fcx[KF] = {f2.x, f2.y, f2.z, f2.w, f2b.x, f2b.y, f2b.z, f2b.w};
 #pragma unroll
-                    for (int j = 0; j < KF; ++j) {
-                        if (j < nfxw) {
-                            const bool on = !LONG || (uint32_t)j < nfx;   // (LONG: the last slots may hold long entries, not in the history; else absent slots have cost +inf)
-                            from_history(on ? fdx[j] : 1u, on ? fcx[j] : INFINITY, Mf, Xf);
+                        for (int j = 0; j < KF; ++j) {
+                            if (j < nfxw && ((uint32_t)j % nparts) == part) {
+                                const bool on = !MASK || (uint32_t)j < nfx;   // (MASK: the last slots may hold long entries, not in the history; else absent slots have cost +inf)
+                                from_history(on ? fdx[j] : 1u, on ? fcx[j] : INFINITY, Mf, Xf);
+                            }
                         }
                     }
-                }
-                if (has_ov) {
-                    const uint32_t nov = PGM_NF_NOV(fxw), ovi = PGM_NF_OVI(fxw) * (uint32_t)PGM_OV_ENT;
-                    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < nov) != 0ull; ++j) {
-                        const bool on = j < nov;
-                        const uint2 e = ovtab[on ? ovi + j : 0u];
-                        from_history(on ? e.x : 1u, on ? __uint_as_float(e.y) : INFINITY, Mf, Xf);
+                    if (has_ov) {
+                        const uint32_t nov = PGM_NF_NOV(fxw), ovi = PGM_NF_OVI(fxw) * (uint32_t)PGM_OV_ENT;
+                        for (uint32_t j = part; __builtin_amdgcn_ballot_w64(j < nov) != 0ull; j += nparts) {
+                            const bool on = j < nov;
+                            const uint2 e = ovtab[on ? ovi + j : 0u];
+                            from_history(on ? e.x : 1u, on ? __uint_as_float(e.y) : INFINITY, Mf, Xf);
+                        }
                     }
-                }
-                if (LONG) {
+                } else {
+                    // ---- long column entries ----
                     const uint32_t nlx = PGM_NF_NLONG(fxw);
                     float4 cq = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-                    if (__builtin_amdgcn_ballot_w64(nlx != 0u) != 0ull) cq = ring3[rslot + 4u];
+                    if (__builtin_amdgcn_ballot_w64(nlx != 0u) != 0ull) cq = ring3[rslot + 4u * (uint32_t)NR];
 #pragma unroll
                     for (int s = 0; s < NL; ++s) {
                         const bool has = nlx > (uint32_t)s;
@@ -1527,44 +1563,43 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                     }
                     issue1(xs + PF, s0);
                 }
-                rs[lane] = Mf; rs[64 + lane] = Xf;
+                if (__builtin_amdgcn_ballot_w64(Mf > PGM_NEG_INF || Xf > PGM_NEG_INF) != 0ull) { fold(rs + lane, Mf); fold(rs + 64 + lane, Xf); }
             } else {
-                rs[lane] = PGM_NEG_INF; rs[128 + lane] = PGM_NEG_INF;
-                // ---- row entries, one entry per lane ----
+                // ---- row entries, one entry per lane; this wavefront's passes: p = part + nparts q ----
 #pragma unroll
-                for (int p = 0; p < KF; ++p) {
-                    const bool fifo = LONG && p < 2;   // (passes 0 and 1 keep their FIFOs moving even without entries)
-                    if (p < npass || fifo) {
-                        const uint32_t o = e_o[p], dy = e_dy[p];
-                        const float cy = e_cy[p];
+                for (int q = 0; q < KQ; ++q) {
+                    const bool fifo = LONG && q == 0;   // (the first pass keeps its FIFO moving even without entries)
+                    if ((int)(part + nparts * (uint32_t)q) * 64 < ne || fifo) {
+                        const uint32_t o = e_o[q], dy = e_dy[q];
+                        const float cy = e_cy[q];
                         const int xo = (int)t - (int)o;
-                        const uint32_t rso = ((uint32_t)xo & (uint32_t)(NR - 1)) * (uint32_t)RS;
+                        const uint32_t rso = (uint32_t)xo & (uint32_t)(NR - 1);
                         const float4 cno = ring3[rso];
                         const float So = sblk[i * 64 + (int)o];
                         const float gopen_y = (xo == 0) ? sg : gi;
-                        const bool rem = fifo && e_rem[p];
+                        const bool rem = fifo && e_rem;
                         const uint32_t s1 = t - dy, lp = rem ? 0u : (uint32_t)VL + o - dy;
                         float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
                         float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
                         if (fifo) {
-                            const float2 cur = rf[p][s0];
+                            const float2 cur = rf[s0];
                             const bool cv = rem && (uint32_t)xo < ncol;
                             const float Wr = cv ? cur.x : PGM_NEG_INF;
-                            rw[p][s0] = Wr;
-                            if (rem) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[p][sm1]; W2 = rw[p][sm2]; W3 = rw[p][sm3]; }
-                            issue2(p, xo + PF, s0);
+                            rw[s0] = Wr;
+                            if (rem) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[sm1]; W2 = rw[sm2]; W3 = rw[sm3]; }
+                            issue2(xo + PF, s0);
                         }
                         const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);
                         float Mt = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, So), cy), cno.x),
                                          fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, So), cy), cno.y), __fsub_rn(__fsub_rn(__fadd_rn(W3, So), cy), cno.z)));
                         // ---- pairs with the far entries of the entry's current column ----
-                        const uint32_t fow = (e_ok[p] && (uint32_t)xo < ncol) ? __float_as_uint(cno.w) : 0u;
+                        const uint32_t fow = (e_ok[q] && (uint32_t)xo < ncol) ? __float_as_uint(cno.w) : 0u;
                         const uint32_t nfo = fow & PGM_NF_COUNT, nlo = LONG ? PGM_NF_NLONG(fow) : 0u, novo = has_ov ? PGM_NF_NOV(fow) : 0u;
                         if (__builtin_amdgcn_ballot_w64((nfo | nlo | novo) != 0u) != 0ull) {
                             const int nw = pgm_wave_max8(nfo);
-                            const float4 g1 = ring3[rso + 1u], g2 = ring3[rso + 3u];
+                            const float4 g1 = ring3[rso + (uint32_t)NR], g2 = ring3[rso + 3u * (uint32_t)NR];
                             float4 g1b = make_float4(0.f, 0.f, 0.f, 0.f), g2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-                            if (nw > 4 || (LONG && __builtin_amdgcn_ballot_w64(nlo != 0u) != 0ull)) { g1b = ring3[rso + 2u]; g2b = ring3[rso + 4u]; }
+                            if (nw > 4 || (LONG && __builtin_amdgcn_ballot_w64(nlo != 0u) != 0ull)) { g1b = ring3[rso + 2u * (uint32_t)NR]; g2b = ring3[rso + 4u * (uint32_t)NR]; }
                             const uint32_t gdx[KF] = {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w),
                                                       __float_as_uint(g1b.x), __float_as_uint(g1b.y), __float_as_uint(g1b.z), __float_as_uint(g1b.w)};
                             const float gcx[KF] = {g2.x, g2.y, g2.z, g2.w, g2b.x, g2b.y, g2b.z, g2b.w};
@@ -1590,7 +1625,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                                 // the loads of the eight slots together, then the overflow entries of a remote row one by one
                                 const bool dem = (rem && (nfo | novo) != 0u) || nlo != 0u;
                                 if (__builtin_amdgcn_ballot_w64(dem) != 0ull) {
-                                    const uint32_t sb = rem ? e_off[p] : row_off(64u * b + o - dy);
+                                    const uint32_t sb = rem ? e_off : row_off(64u * b + o - dy);
                                     float Wq[KF];
                                     bool onq[KF];
 #pragma unroll
@@ -1613,15 +1648,12 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                                 }
                             }
                         }
-                        if (e_ok[p]) {
-                            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(rs + o), Mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-                            __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)(rs + 128 + o), Yt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
-                        }
+                        if (e_ok[q]) { fold(rs + o, Mt); fold(rs + 128 + o, Yt); }
                     }
                 }
             }
             asm volatile("" ::: "memory");
-            __hip_atomic_store(sw + 1 + GROUP, (int)t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sw + hidx, (int)t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -1629,7 +1661,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 // NOTRACEBACK = true: timing build for tools (the fill alone, no traceback); DBG = true: timeline (PGM_FILL_TRACE) and the
 // experiment switches of PGM_TEST_NOSTORE
 template <bool NOTRACEBACK, bool DBG>
-__global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
+__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace,
                                                       uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_) {
     const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
@@ -1638,19 +1670,19 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
     // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
     __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
     __shared__ int item_lds, tb_go;
-    __shared__ int fsync[4];       // MODE 2 item: {last recorded step + 2, terms published by helper groups 0, 1, 2}
+    __shared__ __attribute__((aligned(16))) int fsync[12];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built
     static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
     for (;;) {
-        // next item of the list (all four wavefronts take the same one)
+        // next item of the list (all wavefronts of the worker take the same one)
         __syncthreads();
         if (threadIdx.x == 0) {
             int it = -1;
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
-            fsync[0] = 0; fsync[1] = 0; fsync[2] = 0; fsync[3] = 0;
+            for (int k = 0; k < 12; ++k) fsync[k] = 0;
         }
         __syncthreads();
         const int it = item_lds;
@@ -1667,7 +1699,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         const bool last_band = (item.band + item.count == J.nb);
         const unsigned long long clk0 = (DBG && trace) ? __builtin_readcyclecounter() : 0ull;
         if ((uint32_t)role < item.count) {
-            unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helper
+            unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helpers
             const bool stall = item.job == stall_job && b == stall_band;
             uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
             if (J.mode2) pgm_sweep_band<2, DBG>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, trace ? wait_ticks : nullptr, fsync, dbg_flags);
@@ -1677,21 +1709,26 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
         } else if (J.mode2 && !(dbg_flags & 4u)) {
             // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts
             __builtin_amdgcn_s_setprio(0);
-            if (role == 1) { if (!(dbg_flags & 32u)) pgm_terms_helper<0, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 1024u) ? 2 : 0); }
+            if (role <= 2) { if (!(dbg_flags & 32u)) pgm_terms_helper<0, false>(J, item.band, L.pool, lane, fsync, role, (uint32_t)(role - 1), 2u); }
             else if (J.has_far && !(dbg_flags & 16u)) {
-                if (role == 2) {
-                    if (J.long2) pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
-                    else pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                // wavefront 4 shares its SIMD with the sweeping wavefront 0: it gets the part that usually has the least to do
+                // (the last third of the row entry passes); column helpers: wavefronts 3 and 7, row helpers: 5, 6, 4
+                if (role == 3 || role == 7) {
+                    const uint32_t part = role == 3 ? 0u : 1u;
+                    if (!J.long2) pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, role, part, 2u, (dbg_flags & 256u) != 0);
+                    else if (part == 0u) pgm_terms_helper<1, false, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
+                    else pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
                 } else {
-                    if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
-                    else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, (dbg_flags & 2048u) ? 2 : 0);
+                    const uint32_t part = role == 4 ? 2u : (uint32_t)(role - 5);
+                    if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 256u) != 0);
+                    else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 256u) != 0);
                 }
             }
         }
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         if (last_band) {
             // The last band of a job is the last one to finish, and every cell of the job is written through to memory
-            // by now: this worker walks the traceback (all four wavefronts, whatever they did in this item).
+            // by now: this worker walks the traceback (all its wavefronts, whatever they did in this item).
             __syncthreads();
             if (threadIdx.x == 0) {
                 const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
@@ -1701,7 +1738,7 @@ __global__ void __launch_bounds__(256, 2) pgm_fill_kernel(const PgmJob *__restri
             __syncthreads();
             if (tb_go != 0 && !NOTRACEBACK) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
-                pgm_traceback_job(J, L.t, (int)threadIdx.x, 256, trace ? trace + 6 * it + 4 : nullptr);
+                pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
             }
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         }

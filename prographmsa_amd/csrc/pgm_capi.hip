@@ -420,9 +420,9 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // timing experiments only (results are garbage): 1 = the cell stores are dropped, 2 = the sweeping wavefront of a MODE 2 band
     // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
     const uint32_t dbg_flags = getenv("PGM_TEST_NOSTORE") ? (uint32_t)atoi(getenv("PGM_TEST_NOSTORE")) : 0u;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
-    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(256), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
@@ -553,7 +553,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 J.long1 = (J.mode2 && o.s1.remote) ? 1u : 0u;
                 J.long2 = (J.mode2 && o.s2.remote) ? 1u : 0u;
                 J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
-                J.nslots = J.mode2 ? 1u : std::max(1u, std::min(4u, (uint32_t)PGM_POOL / J.slot_bytes));
+                J.nslots = J.mode2 ? 1u : std::max(1u, std::min((uint32_t)PGM_WAVES, (uint32_t)PGM_POOL / J.slot_bytes));
                 if (job_stats) {   // tools: how the nodes of this job are served
                     uint32_t gen[2] = {0, 0}, lng = 0;
                     for (int side = 0; side < 2; ++side) {
@@ -655,18 +655,18 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     // job is complete: the lags still ahead, one full sweep, the traceback).  Within a job the items keep ascending
     // order, as the kernel requires; taking only ready items keeps workers from idling in front of a predecessor band.
     // Step times (us, measured with the whole batch resident): ~0.45 for a chain-only band (the leaf level is bound by the
-    // HBM write bandwidth), ~0.65 with the near window and the far history in the sweeping wavefront, ~0.4 with helpers.
+    // HBM write bandwidth), ~0.65 with the near window and the far history in the sweeping wavefront, ~0.6 with helpers.
     std::vector<PgmItem> items;
-    uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount * 2u;
-    // persistent workers: 2 workgroups of 4 wavefronts per CU (each owns half of the CU's LDS for its sweeps' histories)
+    uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount;
+    // persistent workers: one workgroup of 8 wavefronts per CU (it owns the CU's LDS for its sweeps' histories)
     if (const char *env_c = getenv("PGM_FILL_WORKERS"))   // experiments only
-        capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount * 2u, (uint32_t)std::max(1, atoi(env_c)));
+        capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount, (uint32_t)std::max(1, atoi(env_c)));
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
         std::vector<std::vector<Item>> per_job(njobs);
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };   // experiments only
-        const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.4), eager = envd("PGM_SIM_EAGER", 0.7);
+        const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
         size_t total = 0;
         double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {

@@ -14,14 +14,16 @@
 #define PGM_KF8 8          /* ... by the far helper of a MODE 2 sweep */
 #define PGM_DCAP 28        /* largest predecessor distance served from the on-chip history (farther: cell storage) */
 #define PGM_PF 4           /* MODE 2: the far helpers load the sources of long / remote entries this many steps ahead */
-#define PGM_REMOTE_MAX 128 /* MODE 2: remote row entries per band served by the far helper (two per lane) */
-#define PGM_POOL 81408     /* LDS bytes of a fill worker (two workers per CU: 2 x (81408 + 512) = 160 KiB) */
-/* extra LDS of a MODE 2 sweep (PgmJob::mode2: three helper wavefronts evaluate all but the chain terms), at PgmJob::aux_off: */
-#define PGM_AUX_RES 0      /* float res[3 groups][4][3][64]: partial maxima {M, X, Y} per lane of the steps t & 3, per helper group */
-#define PGM_AUX_SBLK 9216  /* float sblk[8][64]: emission scores of the far helper's current block (entry lanes read their owner's) */
-#define PGM_AUX_EL 11264   /* uint2 elist[512]: far row entries of the band {owner lane | distance << 8, cost} */
-#define PGM_AUX_CNT 15360  /* int[2]: number of remote entries, number of local entries */
-#define PGM_AUX_BYTES 15376
+#define PGM_REMOTE_MAX 128 /* MODE 2: remote row entries per band served by the row helpers (passes 0 and 1) */
+#define PGM_WAVES 8        /* wavefronts of a fill worker (one 512-thread workgroup per CU) */
+#define PGM_POOL 163584    /* LDS bytes of a fill worker (one worker per CU: 163584 + 256 = 160 KiB) */
+#define PGM_CPARTS 3       /* MODE 2: far helpers of the ROWS (row entry passes p = part + 3 q), 2 each for the near terms and the columns */
+/* extra LDS of a MODE 2 sweep (PgmJob::mode2: seven helper wavefronts evaluate all but the chain terms), at PgmJob::aux_off: */
+#define PGM_AUX_RES 0      /* float res[4][3][64]: maxima {M, X, Y} per lane of the steps t & 3 over all helpers (LDS float-max atomics; reset by the sweep) */
+#define PGM_AUX_SBLK 3072  /* float sblk[3][8][64]: emission scores of the current block of each row helper (entry lanes read their owner's) */
+#define PGM_AUX_EL 9216    /* uint2 elist[512]: far row entries of the band {owner lane | distance << 8 | remote << 31, cost} */
+#define PGM_AUX_CNT 13312  /* int[2]: number of remote entries, number of local entries */
+#define PGM_AUX_BYTES 13328
 
 // Per-node predecessor summary prepared by the host from the CSR (80 bytes = 5 float4).
 //   q0 = {cc, c2, c3, flags}   q1 = {fd0..fd3}   q2 = {fd4..fd7}   q3 = {fc0..fc3}   q4 = {fc4..fc7}
