@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 // Columns with more on-chip entries than the summary holds keep the rest in an overflow table (LDS copy, any helper).
 template <int GROUP, bool LONG, bool MASK = false>   // MASK: the column summaries of this job may hold long entries in their last slots
 __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic,
-                                                 const int hidx, const uint32_t part, const uint32_t nparts, const bool idle = false) {
+                                                 const int hidx, const uint32_t part, const uint32_t nparts, const bool idle = false, const bool nofold = false, unsigned long long *hst = nullptr) {
     constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5, PF = PGM_PF, NL = PGM_NLONG, KQ = 3;
     static_assert(PF == 4 && BL == 8, "FIFO slots are indexed with i & 3");
     static_assert(PGM_DCAP + 1 - (4 + PF) >= 16 + 3, "a long source must be stored before the sweep's last counted wait");
@@ -1333,7 +1333,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     const uint32_t ncol_row = rowvalid ? ncol : 0u;
     const float4 *S_band = (const float4 *)(J.S + (size_t)b * nblk * 64u * BL);
     const uint32_t lb = (uint32_t)(VL + lane);
-    auto fold = [&](float *p, float v) { __builtin_amdgcn_ds_fmaxf((pgm_lds_float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false); };
+    auto fold = [&](float *p, float v) { if (nofold) return; __builtin_amdgcn_ds_fmaxf((pgm_lds_float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false); };
     // cell (r, c) of the job = byte offset row_off(r) + c * 1024 into the job's cell storage (32-bit: the host only
     // marks entries long / remote when the job's storage is smaller than 4 GiB)
     const __amdgpu_buffer_rsrc_t job_rsrc = pgm_band_rsrc(J.cells, LONG ? J.nb * tsteps * 1024u : 16u);
@@ -1348,6 +1348,10 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     // GROUP 2: entry list of the band, remote entries first (order irrelevant otherwise), built by part 0.  LDS operations of
     // one wavefront execute in order.
     int ne = 0;
+    // a band whose entries fit one pass (the usual case): wavefront part 0 takes the Y term and the near pairs of that pass, part 1
+    // the pairs with the far edges of the columns, part 2 nothing; otherwise part k takes the whole passes k, k + 3, k + 6
+    bool single = false;
+    auto p_of = [&](int q) { return single ? (q == 0 && part < 2u ? 0u : 64u) : part + nparts * (uint32_t)q; };
     uint32_t e_o[KQ], e_dy[KQ];
     float e_cy[KQ];
     bool e_ok[KQ], e_rem = false;
@@ -1378,9 +1382,10 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
         const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const int totL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         ne = min(totR + totL, 512);   // (the host keeps a band within 512 entries and PGM_REMOTE_MAX remote ones)
+        single = !LONG && ne <= 64;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-            const int idx = (int)(part + nparts * (uint32_t)q) * 64 + lane;
+            const int idx = (int)p_of(q) * 64 + lane;
             e_ok[q] = idx < ne;
             const uint2 a = e_ok[q] ? elist[idx] : make_uint2((uint32_t)lane | (1u << 8), __float_as_uint(INFINITY));
             e_o[q] = a.x & 255u; e_dy[q] = (a.x >> 8) & 0x7fffffu; e_cy[q] = __uint_as_float(a.y);
@@ -1390,7 +1395,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             }
         }
     }
-    if (GROUP == 2 && !LONG && (int)part * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
+    const bool do_near = !single || part == 0u, do_pairs = !single || part == 1u;
+    if (GROUP == 2 && !LONG && (int)p_of(0) * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
         __hip_atomic_store(sw + hidx, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
@@ -1447,6 +1453,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     };
     load_s_block(0);
     int seen = 0;
+    unsigned long long hwait = 0;
+    const unsigned long long ht0 = hst ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (LONG && GROUP != 0) {   // the FIFOs are primed once the sweep's prologue is done (column ring staged)
         while (seen < 1) {
             seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1474,8 +1482,10 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             const int need = max(1, (int)t - slack + 2);
             while (seen < need) {   // (a sleeping poll: a tight one would keep the CU's LDS pipeline and this SIMD's issue slots busy;
                                     //  the far helpers have three steps of lead, the wavefront of the step t - 3 term has none to give away)
+                const unsigned long long w0 = hst ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (seen < need) { if (GROUP == 0) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }
+                if (hst) hwait += __builtin_amdgcn_s_memrealtime() - w0;
             }
             asm volatile("" ::: "memory");
             const int xs = (int)t - lane;
@@ -1569,7 +1579,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
                     const bool fifo = LONG && q == 0;   // (the first pass keeps its FIFO moving even without entries)
-                    if ((int)(part + nparts * (uint32_t)q) * 64 < ne || fifo) {
+                    if ((int)p_of(q) * 64 < ne || fifo) {
                         const uint32_t o = e_o[q], dy = e_dy[q];
                         const float cy = e_cy[q];
                         const int xo = (int)t - (int)o;
@@ -1579,8 +1589,11 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                         const float gopen_y = (xo == 0) ? sg : gi;
                         const bool rem = fifo && e_rem;
                         const uint32_t s1 = t - dy, lp = rem ? 0u : (uint32_t)VL + o - dy;
-                        float Yh = hY[(s1 & Dm) * HS + lp], Wh = hW[(s1 & Dm) * HS + lp];
-                        float W1 = hW[((s1 - 1u) & Dm) * HS + lp], W2 = hW[((s1 - 2u) & Dm) * HS + lp], W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                        float Yh = PGM_NEG_INF, Wh = PGM_NEG_INF, W1 = PGM_NEG_INF, W2 = PGM_NEG_INF, W3 = PGM_NEG_INF;
+                        if (do_near) {
+                            Yh = hY[(s1 & Dm) * HS + lp]; Wh = hW[(s1 & Dm) * HS + lp];
+                            W1 = hW[((s1 - 1u) & Dm) * HS + lp]; W2 = hW[((s1 - 2u) & Dm) * HS + lp]; W3 = hW[((s1 - 3u) & Dm) * HS + lp];
+                        }
                         if (fifo) {
                             const float2 cur = rf[s0];
                             const bool cv = rem && (uint32_t)xo < ncol;
@@ -1589,13 +1602,13 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             if (rem) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[sm1]; W2 = rw[sm2]; W3 = rw[sm3]; }
                             issue2(xo + PF, s0);
                         }
-                        const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);
+                        const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);   // (-inf without the near part)
                         float Mt = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W1, So), cy), cno.x),
                                          fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(W2, So), cy), cno.y), __fsub_rn(__fsub_rn(__fadd_rn(W3, So), cy), cno.z)));
                         // ---- pairs with the far entries of the entry's current column ----
                         const uint32_t fow = (e_ok[q] && (uint32_t)xo < ncol) ? __float_as_uint(cno.w) : 0u;
                         const uint32_t nfo = fow & PGM_NF_COUNT, nlo = LONG ? PGM_NF_NLONG(fow) : 0u, novo = has_ov ? PGM_NF_NOV(fow) : 0u;
-                        if (__builtin_amdgcn_ballot_w64((nfo | nlo | novo) != 0u) != 0ull) {
+                        if (do_pairs && __builtin_amdgcn_ballot_w64((nfo | nlo | novo) != 0u) != 0ull) {
                             const int nw = pgm_wave_max8(nfo);
                             const float4 g1 = ring3[rso + (uint32_t)NR], g2 = ring3[rso + 3u * (uint32_t)NR];
                             float4 g1b = make_float4(0.f, 0.f, 0.f, 0.f), g2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
@@ -1656,6 +1669,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             __hip_atomic_store(sw + hidx, (int)t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    if (hst && lane == 0) { hst[hidx] = hwait; hst[8 + hidx] = __builtin_amdgcn_s_memrealtime() - ht0; }   // timeline: ticks in the poll loop, ticks in all
 }
 
 // NOTRACEBACK = true: timing build for tools (the fill alone, no traceback); DBG = true: timeline (PGM_FILL_TRACE) and the
@@ -1709,19 +1723,20 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
         } else if (J.mode2 && !(dbg_flags & 4u)) {
             // helpers of the sweeping wavefront 0 (a MODE 2 item is one band); they yield issue slots to sweeping wavefronts
             __builtin_amdgcn_s_setprio(0);
-            if (role <= 2) { if (!(dbg_flags & 32u)) pgm_terms_helper<0, false>(J, item.band, L.pool, lane, fsync, role, (uint32_t)(role - 1), 2u); }
+            unsigned long long *hst = trace ? trace + 6 * (size_t)nitems + 16 * (size_t)it : nullptr;
+            if (role <= 2) { if (!(dbg_flags & 32u)) pgm_terms_helper<0, false>(J, item.band, L.pool, lane, fsync, role, (uint32_t)(role - 1), 2u, false, false, hst); }
             else if (J.has_far && !(dbg_flags & 16u)) {
                 // wavefront 4 shares its SIMD with the sweeping wavefront 0: it gets the part that usually has the least to do
                 // (the last third of the row entry passes); column helpers: wavefronts 3 and 7, row helpers: 5, 6, 4
                 if (role == 3 || role == 7) {
                     const uint32_t part = role == 3 ? 0u : 1u;
-                    if (!J.long2) pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, role, part, 2u, (dbg_flags & 256u) != 0);
+                    if (!J.long2) pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, role, part, 2u, (dbg_flags & 256u) != 0, (dbg_flags & 2048u) != 0, hst);
                     else if (part == 0u) pgm_terms_helper<1, false, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
                     else pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
                 } else {
                     const uint32_t part = role == 4 ? 2u : (uint32_t)(role - 5);
                     if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 256u) != 0);
-                    else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 256u) != 0);
+                    else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 512u) != 0, (dbg_flags & 2048u) != 0, hst);
                 }
             }
         }

@@ -717,7 +717,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     }
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
-    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 48 * items.size());
+    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 176 * items.size());   // 6 words per item + 16 per item for the helper wavefronts
     if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -779,9 +779,9 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
-        std::vector<unsigned long long> tr(6 * (size_t)b->nitems);
+        std::vector<unsigned long long> tr(22 * (size_t)b->nitems);
         std::vector<PgmItem> its(b->nitems);
-        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 48 * (size_t)b->nitems, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 176 * (size_t)b->nitems, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(its.data(), b->d_items, sizeof(PgmItem) * b->nitems, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(getenv("PGM_FILL_TRACE") ? getenv("PGM_FILL_TRACE") : "/dev/null", "wb")) {
             fwrite(&b->nitems, 4, 1, f); fwrite(its.data(), sizeof(PgmItem), b->nitems, f); fwrite(tr.data(), 8, tr.size(), f); fclose(f);

@@ -77,3 +77,11 @@ for name, sel in (("root", np.argmax(sizes[:, 0] * sizes[:, 1])),):
         if tend[i] == 0 and raw[i, 5] > 0:
             print("   band %2d: %.0f shader cycles in %.0f us = %.2f GHz" % (items[i, 1], float(raw[i, 5]), bend[i] - start[i], float(raw[i, 5]) / (bend[i] - start[i]) / 1e3))
         print("   band %2d: start %6.0f  wait %6.0f  end %6.0f  (running %.0f us = %.3f us/step; of which waiting for the helper %.0f us)" % (items[i, 1], start[i], wait_us[i], bend[i], bend[i] - start[i] - wait_us[i], (bend[i] - start[i] - wait_us[i]) / steps[i], raw[i, 4] / 100.0 if tend[i] == 0 else -1))
+
+# helper wavefronts of the root's bands (MODE 2): share of their time spent polling for the sweep (ticks of 10 ns)
+if len(buf) >= 4 + 16 * n + 8 * 22 * n:
+    hs = np.frombuffer(buf, np.uint64, 16 * n, 4 + 16 * n + 48 * n).reshape(n, 16).astype(np.float64)
+    m = items[:, 0] == np.argmax(sizes[:, 0] * sizes[:, 1])
+    tot, wt = hs[m][:, 8:16].mean(0), hs[m][:, 0:8].mean(0)
+    print("root bands, helper wavefronts 1..7: mean us in all   " + " ".join("%7.0f" % (v / 100) for v in tot[1:]))
+    print("                                   of which polling " + " ".join("%7.0f" % (v / 100) for v in wt[1:]))
