@@ -1274,11 +1274,11 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 //   GROUP 0  (wavefronts 1, 2) the near terms the sweep does not hold in registers, one row per lane like the sweep: Y from
 //            row y-3 (part 0: the only helper term that reads step t - 3, slack 3), the six M pairs of rows y-1..y-3 x
 //            columns x-1..x-3 that read step t - 4 or older (part 1, slack 4)
-//   GROUP 1  (wavefronts 3, 4) the far edges of the COLUMNS, one row per lane (a column's far edges pass down the lanes one
+//   GROUP 1  (wavefronts 3, 7) the far edges of the COLUMNS, one row per lane (a column's far edges pass down the lanes one
 //            step at a time): X term, M terms with the three near rows.  On-chip entries (summary slots and the overflow
-//            table): every other one each; in a job with long column entries wavefront 3 takes all on-chip entries and
-//            wavefront 4 (LONG) the long ones
-//   GROUP 2  (wavefronts 5-7) the far edges of the ROWS, one (row, far edge) ENTRY per lane — a band has a handful of them,
+//            table): every other one each; in a job with long column entries the first one takes all on-chip entries and the
+//            second one (LONG) the long ones
+//   GROUP 2  (wavefronts 5, 6, 4) the far edges of the ROWS, one (row, far edge) ENTRY per lane — a band has a handful of them,
 //            a lane per row would loop to the largest count per row for all 64 rows: Y term, M terms with the three near
 //            columns and with the far edges of the entry's current column.  Part k takes the passes k, k + 3, k + 6 of the
 //            band's entry list.
@@ -1522,7 +1522,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                 };
                 const uint32_t fxw = (uint32_t)xs < ncol_row ? __float_as_uint(cn.w) : 0u;
                 float Mf = PGM_NEG_INF, Xf = PGM_NEG_INF;
-                if (!LONG) {
+                if (nparts != 0u) {
                     // ---- on-chip column entries, one row per lane; this wavefront's share: entries j = part, part + nparts, ... ----
                     const uint32_t nfx = fxw & PGM_NF_COUNT;
                     if (__builtin_amdgcn_ballot_w64(nfx > part) != 0ull) {
@@ -1536,7 +1536,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 #pragma unroll
                         for (int j = 0; j < KF; ++j) {
                             if (j < nfxw && ((uint32_t)j % nparts) == part) {
-                                const bool on = !MASK || (uint32_t)j < nfx;   // (MASK: the last slots may hold long entries, not in the history; else absent slots have cost +inf)
+                                const bool on = !(MASK || LONG) || (uint32_t)j < nfx;   // (MASK: the last slots may hold long entries, not in the history; else absent slots have cost +inf)
                                 from_history(on ? fdx[j] : 1u, on ? fcx[j] : INFINITY, Mf, Xf);
                             }
                         }
@@ -1549,7 +1549,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             from_history(on ? e.x : 1u, on ? __uint_as_float(e.y) : INFINITY, Mf, Xf);
                         }
                     }
-                } else {
+                }
+                if (LONG) {
                     // ---- long column entries ----
                     const uint32_t nlx = PGM_NF_NLONG(fxw);
                     float4 cq = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
@@ -1731,11 +1732,11 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
                 if (role == 3 || role == 7) {
                     const uint32_t part = role == 3 ? 0u : 1u;
                     if (!J.long2) pgm_terms_helper<1, false>(J, item.band, L.pool, lane, fsync, role, part, 2u, (dbg_flags & 256u) != 0, (dbg_flags & 2048u) != 0, hst);
-                    else if (part == 0u) pgm_terms_helper<1, false, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
-                    else pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0);
+                    else if (part == 0u) pgm_terms_helper<1, false, true>(J, item.band, L.pool, lane, fsync, role, 0u, 1u, (dbg_flags & 256u) != 0, false, hst);
+                    else pgm_terms_helper<1, true>(J, item.band, L.pool, lane, fsync, role, 0u, 0u, (dbg_flags & 256u) != 0, false, hst);   // (nparts = 0: the long entries only)
                 } else {
                     const uint32_t part = role == 4 ? 2u : (uint32_t)(role - 5);
-                    if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 256u) != 0);
+                    if (J.long1 | J.long2) pgm_terms_helper<2, true>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 512u) != 0, false, hst);
                     else pgm_terms_helper<2, false>(J, item.band, L.pool, lane, fsync, role, part, (uint32_t)PGM_CPARTS, (dbg_flags & 512u) != 0, (dbg_flags & 2048u) != 0, hst);
                 }
             }
