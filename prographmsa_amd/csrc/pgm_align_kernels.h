@@ -156,8 +156,8 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 // Emission kernel (GraphAlign.h:145-163 precomputeScores, fused with ls_log_add): S for every cell, written
 // in the skewed (band, step, lane) order in which the fill kernel consumes it.  No dependencies between
 // cells, so this part of the reference's per-cell work runs at full occupancy, off the DP's critical path.
-// grid = (ceil(nblk / 4), ceil(nb / 4), njobs); block = 256 threads: thread T owns row T % 64 of band 4 blockIdx.y + T / 64
-// and computes its cells of PGM_EM_TB = 4 step blocks (columns t - l, l = T % 64).
+// grid = (ceil(nblk / 4), ceil(nb / (4 RB)), njobs); block = 256 threads: thread T owns row T % 64 of the RB bands
+// (4 blockIdx.y + T / 64) RB + r and computes their cells of PGM_EM_TB = 4 step blocks (columns t - l, l = T % 64).
 // The 95 columns of T = M^T g2 the workgroup touches are staged in LDS as overlapping column PAIRS
 // {T[c][k], T[c+1][k]}: two consecutive cells of a row are then one packed multiply and one packed add per k
 // (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, the same sequential mul-then-add order as the scalar code).
@@ -167,16 +167,19 @@ __device__ __forceinline__ float pgm_dpp_wave_shr1(float src, float lane0_value)
 typedef float pgm_v4f __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T pgm_gld(const T *p) { return *(const PGM_GLOBAL T *)(uintptr_t)p; }   // scalar global load
 #define PGM_EM_TB 4   // step blocks per emission workgroup
-template <int DP>
+template <int DP, int RB>   // RB: rows (bands) per thread — one LDS read of a column pair serves 2 RB cells
 __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const PgmJob *__restrict__ jobs) {
     typedef float pgm_v2f __attribute__((ext_vector_type(2)));
     constexpr int NT = DP / 4;
     constexpr int COLS = 64 + PGM_EM_TB * PGM_BLOCK - PGM_HALO - 1;   // columns [t0 - 63, t0 + PGM_EM_TB * PGM_BLOCK - 1 - PGM_HALO]
-    __shared__ pgm_v2f tp[(COLS + 1) * DP];      // tp[c * DP + k] = {T[c][k], T[c+1][k]} (row COLS is scratch)
+    // (row stride DP + 1 pairs: lane l reads row ci - l, and with a stride of DP pairs — 128 dwords for 64 states — every lane of
+    // a wavefront would hit the same LDS banks)
+    constexpr int STR = DP + 1;
+    __shared__ pgm_v2f tp[(COLS + 1) * STR];     // tp[c * STR + k] = {T[c][k], T[c+1][k]} (row COLS is scratch)
     __shared__ float bq[COLS];
     const PgmJob &J = jobs[blockIdx.z];
     const uint32_t tb0 = blockIdx.x * PGM_EM_TB;
-    if (tb0 >= J.nblk || 4u * blockIdx.y >= J.nb) return;
+    if (tb0 >= J.nblk || 4u * RB * blockIdx.y >= J.nb) return;
     const uint32_t t0 = tb0 * PGM_BLOCK;
     const int cbase = (int)t0 - 63;
     // one float4 load per (column, 4 k): the value T[c][k] is the low half of pair c and the high half of pair c - 1
@@ -190,8 +193,8 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = 4 * q + u;
-            if (ci < COLS) tpf[2 * (ci * DP + k)] = vv[u];
-            if (ci > 0) tpf[2 * ((ci - 1) * DP + k) + 1] = vv[u];
+            if (ci < COLS) tpf[2 * (ci * STR + k)] = vv[u];
+            if (ci > 0) tpf[2 * ((ci - 1) * STR + k) + 1] = vv[u];
         }
     }
     for (int i = threadIdx.x; i < COLS; i += 4 * PGM_ROWS) {
@@ -199,21 +202,22 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
         bq[i] = (col >= 0 && col <= (int)J.ncol) ? J.b2[col] : 0.f;
     }
     __syncthreads();
-    const uint32_t b = 4u * blockIdx.y + threadIdx.x / PGM_ROWS;
+    const uint32_t b0 = (4u * blockIdx.y + threadIdx.x / PGM_ROWS) * RB;   // this thread's bands: b0 .. b0 + RB - 1 (same lane, same columns)
     const int l = PGM_HALO + (int)(threadIdx.x % PGM_ROWS);
-    if (b >= J.nb) return;
-    const uint32_t y = PGM_ROWS * b + (uint32_t)(l - PGM_HALO);
-    const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
-    float gy[DP];
-    {
+    if (b0 >= J.nb) return;
+    float gy[RB][DP], ay[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const uint32_t y = PGM_ROWS * (b0 + (uint32_t)r) + (uint32_t)(l - PGM_HALO);
+        const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
         const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const float4 v = src[q];
-            gy[4 * q] = v.x; gy[4 * q + 1] = v.y; gy[4 * q + 2] = v.z; gy[4 * q + 3] = v.w;
+            gy[r][4 * q] = v.x; gy[r][4 * q + 1] = v.y; gy[r][4 * q + 2] = v.z; gy[r][4 * q + 3] = v.w;
         }
+        ay[r] = J.a1[yc];
     }
-    const float ay = J.a1[yc];
     const float mi = J.sc.match_init;
     const uint32_t nblk = J.nblk;
     PGM_GLOBAL pgm_v4f *const Sq = (PGM_GLOBAL pgm_v4f *)(uintptr_t)J.S;
@@ -221,23 +225,37 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     for (int w = 0; w < PGM_EM_TB; ++w) {
         const uint32_t tb = tb0 + w;
         if (tb >= nblk) break;
-        float out[PGM_BLOCK];
+        float out[RB][PGM_BLOCK];
 #pragma unroll
         for (int i = 0; i < PGM_BLOCK; i += 2) {
             const int ci = (int)(tb * PGM_BLOCK) + i - l - cbase;   // column of cell i in the staged window; cell i + 1: column ci + 1
-            const pgm_v2f *tc = tp + ci * DP;
-            pgm_v2f acc = {0.0f, 0.0f};
+            const pgm_v2f *tc = tp + ci * STR;
+            pgm_v2f acc[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = pgm_v2f{0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < DP; ++k) {
-                const pgm_v2f g = {gy[k], gy[k]};
-                acc = acc + g * tc[k];
-            }
-            out[i] = pgm_emission_finish(acc.x, ay, bq[ci], mi);
-            out[i + 1] = pgm_emission_finish(acc.y, ay, bq[ci + 1], mi);
-        }
-        PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)b * nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
+                const pgm_v2f tk = tc[k];
 #pragma unroll
-        for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
+                for (int r = 0; r < RB; ++r) {
+                    const pgm_v2f g = {gy[r][k], gy[r][k]};
+                    acc[r] = acc[r] + g * tk;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                out[r][i] = pgm_emission_finish(acc[r].x, ay[r], bq[ci], mi);
+                out[r][i + 1] = pgm_emission_finish(acc[r].y, ay[r], bq[ci + 1], mi);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (b0 + (uint32_t)r < J.nb) {
+                PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)(b0 + (uint32_t)r) * nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
+#pragma unroll
+                for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[r][4 * q], out[r][4 * q + 1], out[r][4 * q + 2], out[r][4 * q + 3]};
+            }
+        }
     }
 }
 
