@@ -1366,10 +1366,10 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     // GROUP 2: entry list of the band, remote entries first (order irrelevant otherwise), built by part 0.  LDS operations of
     // one wavefront execute in order.
     int ne = 0;
-    // a band whose entries fit one pass (the usual case): wavefront part 0 takes the Y term and the near pairs of that pass, part 1
-    // the pairs with the far edges of the columns, part 2 nothing; otherwise part k takes the whole passes k, k + 3, k + 6
+    // a band whose entries fit one pass (the usual case): wavefront part 0 takes the Y term and the near pairs of that pass, parts 1
+    // and 2 the pairs with every other far edge of the columns; otherwise part k takes the whole passes k, k + 3, k + 6
     bool single = false;
-    auto p_of = [&](int q) { return single ? (q == 0 && part < 2u ? 0u : 64u) : part + nparts * (uint32_t)q; };
+    auto p_of = [&](int q) { return single ? (q == 0 ? 0u : 64u) : part + nparts * (uint32_t)q; };
     uint32_t e_o[KQ], e_dy[KQ];
     float e_cy[KQ];
     bool e_ok[KQ], e_rem = false;
@@ -1413,7 +1413,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
             }
         }
     }
-    const bool do_near = !single || part == 0u, do_pairs = !single || part == 1u;
+    const bool do_near = !single || part == 0u, do_pairs = !single || part >= 1u;
+    const uint32_t pj0 = single ? part - 1u : 0u, pjs = single ? 2u : 1u;   // this wavefront's far column entries: j = pj0, pj0 + pjs, ...
     if (GROUP == 2 && !LONG && (int)p_of(0) * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
         __hip_atomic_store(sw + hidx, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
@@ -1627,7 +1628,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                         // ---- pairs with the far entries of the entry's current column ----
                         const uint32_t fow = (e_ok[q] && (uint32_t)xo < ncol) ? __float_as_uint(cno.w) : 0u;
                         const uint32_t nfo = fow & PGM_NF_COUNT, nlo = LONG ? PGM_NF_NLONG(fow) : 0u, novo = has_ov ? PGM_NF_NOV(fow) : 0u;
-                        if (do_pairs && __builtin_amdgcn_ballot_w64((nfo | nlo | novo) != 0u) != 0ull) {
+                        if (do_pairs && __builtin_amdgcn_ballot_w64(nfo > pj0 || novo > pj0 || nlo != 0u) != 0ull) {
                             const int nw = pgm_wave_max8(nfo);
                             const float4 g1 = ring3[rso + (uint32_t)NR], g2 = ring3[rso + 3u * (uint32_t)NR];
                             float4 g1b = make_float4(0.f, 0.f, 0.f, 0.f), g2b = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
@@ -1637,7 +1638,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             const float gcx[KF] = {g2.x, g2.y, g2.z, g2.w, g2b.x, g2b.y, g2b.z, g2b.w};
 #pragma unroll
                             for (int j = 0; j < KF; ++j) {
-                                if (j < nw) {
+                                if (j < nw && (pjs == 1u || ((uint32_t)j & 1u) == pj0)) {
                                     const bool on = !LONG || ((uint32_t)j < nfo && !rem);
                                     const float Wp = hW[((s1 - (on ? gdx[j] : 1u)) & Dm) * HS + lp];
                                     Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), on ? gcx[j] : INFINITY));
@@ -1645,7 +1646,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             }
                             const uint32_t ovi = PGM_NF_OVI(fow) * (uint32_t)PGM_OV_ENT;
                             if (has_ov) {
-                                for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < novo && !rem) != 0ull; ++j) {
+                                for (uint32_t j = pj0; __builtin_amdgcn_ballot_w64(j < novo && !rem) != 0ull; j += pjs) {
                                     const bool on = j < novo && !rem;
                                     const uint2 e = ovtab[on ? ovi + j : 0u];
                                     const float Wp = hW[((s1 - (on ? e.x : 1u)) & Dm) * HS + lp];
