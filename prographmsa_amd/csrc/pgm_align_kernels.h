@@ -866,10 +866,11 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 // Fill kernel (GraphAlign.h:212-260 incl. the border initialisation as row/column 0).
 //
 // Work unit = one BAND of one job: 64 consecutive rows of graph 1 against all columns of graph 2, swept by ONE
-// wavefront on its own (no helper wavefronts, no barrier inside a sweep).  Lane l owns row y = 64 b + l and at step t
-// computes column x = t - l: the cells of one step are independent of each other, every predecessor cell was produced
-// by a lower or the same lane at an earlier step.  An item of the work list is up to four consecutive bands of one
-// job, one per wavefront of the worker (512-thread workgroup) that takes it; all bands of all jobs of the batch sit in
+// wavefront (no barrier inside a sweep; MODE 2 adds seven helper wavefronts that only meet it through LDS words).  Lane l
+// owns row y = 64 b + l and at step t computes column x = t - l: the cells of one step are independent of each other,
+// every predecessor cell was produced by a lower or the same lane at an earlier step.  An item of the work list is up to
+// eight consecutive bands of one job, one per wavefront of the worker (512-thread workgroup, one per CU) that takes it,
+// or one band of a MODE 2 job; all bands of all jobs of the batch sit in
 // one list ordered by the host (longest remaining path first), a persistent grid of workers takes them through an
 // atomic ticket.  Band b of a job is always listed after band b-1, so the wavefront it waits for is already running.
 //
@@ -888,15 +889,17 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 //   Rows above the band: the last 16 rows of band b-1 are "virtual lanes" -16..-1 of the history (read back from the
 //       cell storage a block ahead: because of the skew they are ONE contiguous 256 B run per step); lane 0's three
 //       upper neighbours are injected from there (the DPP's `old` operand).
-//   GENERIC (more than PGM_KF far edges, farther than PGM_DCAP or above the virtual lanes): the node's edges are read
-//       from the cell storage through the CSR lists (device-scope loads), as rare as pathological graphs are.
+//   GENERIC (self-contained sweeps: more than PGM_KF far edges, farther than PGM_DCAP or above the virtual lanes; MODE 2:
+//       what the helpers' long / remote entries and the overflow table do not cover, see PgmNode2): the node's edges are
+//       read from the cell storage through the CSR lists (device-scope loads), as rare as pathological graphs are.
 // Bands hand over through the cell storage itself; prog[b] (global, agent scope) = number of steps of band b that are
 // complete AND visible; the producer publishes behind a counted s_waitcnt, never vmcnt(0).
 // MODE 0: chain-only job (every node has at most its chain predecessor): chain terms only, no history of the band's own rows
 // MODE 1: merged graphs, self-contained: near window + far history + generic path in this wavefront
-// MODE 2: merged graphs on the batch's critical path (PgmJob::mode2): this wavefront only evaluates the two terms that
-//         depend on the previous step (chain X, chain Y), merges the partial maxima three helper wavefronts have
-//         prepared a step ahead (pgm_terms_helper), stores the cell and records W, Y, X in the history
+// MODE 2: merged graphs on the batch's critical path or with long edges (PgmJob::mode2): this wavefront only evaluates the
+//         terms it holds in its register windows (chain terms, X from columns x-2 / x-3, Y from row y-2, two M pairs), merges
+//         the maxima seven helper wavefronts have folded ahead of it (pgm_terms_helper), stores the cell and records W, Y, X
+//         in the history
 // DBG = false (production): no timeline accumulators, no experiment switches (their branches and scalar registers are gone)
 template <int MODE, bool DBG>
 __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *abort_flag, bool &aborted,
