@@ -393,6 +393,8 @@ struct PgmTbLds {
     uint32_t ay, ax;                           // walker position the tile was requested for (centre of the link band)
     int req;                                   // 1: stage a tile at (ty0, tx0); 2: walk finished
     uint32_t len;
+    int nbig;                                  // cells of the link band whose nodes have 5..8 predecessors (M link by a whole wavefront)
+    uint16_t big[128];
 };
 
 // predecessor list of one node: either in the tile (LDS) or in memory
@@ -445,6 +447,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             T.S[i] = sv[u];
         }
         for (uint32_t i = (uint32_t)tid; i < 3u * TT * TT / 2u; i += NT) ((uint32_t *)T.succ)[i] = 0u;   // no links yet
+        if (tid == 0) T.nbig = 0;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const uint32_t i = (uint32_t)tid + NT * u, slot = i / PGM_TB_PK, k = i % PGM_TB_PK;
@@ -489,6 +492,12 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 // state M: pairs (row predecessor outer, column predecessor inner)
                 // (cells with more predecessors get no M link: one such cell would hold up the whole tile; the walker
                 // evaluates them itself, one pair per lane, if the path really visits them)
+                const int doff = (int)((task / TT) % NDIAG) - band;   // diagonal relative to the walker's
+                if (st_task == 0u && doff >= -1 && doff <= 1 && (cy > PGM_TB_LK || cx > PGM_TB_LK) && cy <= PGM_TB_PK && cx <= PGM_TB_PK && cy != 0u && cx != 0u && c0.x > PGM_NEG_INF) {
+                    // a node with 5..8 predecessors on one of the three diagonals next to the walker's: see links_big
+                    const int slot = __hip_atomic_fetch_add(&T.nbig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot < 128) T.big[slot] = (uint16_t)ci;
+                }
                 if (st_task == 0u && cy <= PGM_TB_LK && cx <= PGM_TB_LK && cy != 0u && cx != 0u && c0.x > PGM_NEG_INF) {
                     const float S = T.S[ci];
                     // all operands first (the list slots beyond a node's count hold a copy of its last entry, so every read
@@ -571,6 +580,41 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             T.succ[st_task * (TT * TT) + ci] = st_task == 0u ? lm : (st_task == 1u ? lxs : lys);
         }
     };
+    // M links of the band's cells whose nodes have 5..8 predecessors (collected by links(); merged graphs of deep trees have a
+    // few per tile, and without a link each costs the walker 2 us): one wavefront per cell, one candidate pair per lane in
+    // PredIterator order (lane = 8 ky + kx), exactly the walker's evaluation.  No link if a predecessor lies outside the
+    // tile, if no candidate recomputes the stored value exactly, or for a repeat edge: the walker then decides itself.
+    auto links_big = [&]() {
+        const int wave = tid >> 6, lane_b = tid & 63, nwaves = nthreads >> 6;
+        const uint32_t ty0 = T.ty0, tx0 = T.tx0;
+        const int nbig = min(T.nbig, 128);
+        for (int i = wave; i < nbig; i += nwaves) {
+            const uint32_t ci = T.big[i], ly = ci / TT, lx = ci % TT;
+            const uint32_t cy = T.p_cnt[ly], cx = T.p_cnt[TT + lx];
+            const uint32_t ky = (uint32_t)lane_b >> 3, kx = (uint32_t)lane_b & 7u;
+            const bool valid = ky < cy && kx < cx;
+            const uint32_t yp = T.p_c[ly * PGM_TB_PK + ky], xp = T.p_c[(TT + lx) * PGM_TB_PK + kx];
+            const float yv = T.p_v[ly * PGM_TB_PK + ky], xv = T.p_v[(TT + lx) * PGM_TB_PK + kx];
+            const uint32_t rep = T.p_u[ly * PGM_TB_PK + ky] | T.p_u[(TT + lx) * PGM_TB_PK + kx];
+            const bool inside = yp >= ty0 && xp >= tx0;
+            if (__builtin_amdgcn_ballot_w64(valid && !inside) != 0ull) continue;
+            const float4 c0 = T.cell[ci];
+            const float S = T.S[ci];
+            const float4 c = T.cell[(valid && inside) ? (yp - ty0) * TT + (xp - tx0) : ci];
+            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
+            const unsigned long long zero = __builtin_amdgcn_ballot_w64(valid && d == 0.0f);
+            if (zero == 0ull) continue;
+            const int win = __ffsll((long long)zero) - 1;
+            if (lane_b == win && rep == 0u) {
+                uint32_t st = 3u;
+                if ((yp | xp) == 0u) st = 0u;
+                else if (c.z == c.x) st = 0u;
+                else if (c.z == c.w) st = 2u;
+                else if (c.z == c.y) st = 1u;
+                if (st != 3u) T.succ[ci] = (uint16_t)(0x8000u | (st << 10) | ((yp - ty0) << 5) | (xp - tx0));
+            }
+        }
+    };
     if (tid == 0) {
         T.ty0 = n1 - 2 >= TT - 1 ? n1 - 2 - (TT - 1) : 0u;
         T.tx0 = n2 - 2 >= TT - 1 ? n2 - 2 - (TT - 1) : 0u;
@@ -582,6 +626,8 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
     __syncthreads();
     links();
     __syncthreads();
+    links_big();
+    __syncthreads();
 
     if (loader) {
         // ---- loaders (wavefronts 1..): serve the walker's tile requests ----
@@ -591,7 +637,9 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             stage();
             __syncthreads();            // cells, scores, predecessor lists staged
             links();
-            __syncthreads();            // successor table complete
+            __syncthreads();            // successor table complete but for the cells of links_big
+            links_big();
+            __syncthreads();
         }
     } else {
         // ---- walker: wavefront 0, uniform control flow; the one-off END step is evaluated by lane 0 alone ----
@@ -714,7 +762,9 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 __syncthreads();        // cells, scores, predecessor lists staged
                 if (stat) st_stage += __builtin_amdgcn_s_memrealtime() - r0;
                 links();
-                __syncthreads();        // successor table complete
+                __syncthreads();        // successor table complete but for the cells of links_big
+                links_big();
+                __syncthreads();
                 if (stat) { st_reload += __builtin_amdgcn_s_memrealtime() - r0; ++st_nreload; }
             }
             // fast path: follow the precomputed links.  A link's low 12 bits are the table index of the next (state, cell),
