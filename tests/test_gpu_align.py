@@ -58,6 +58,21 @@ def test_random_jobs_bit_exact(ctx, kw, dim):
     b.close()
 
 
+def test_large_heavy_tailed_jobs_bit_exact(ctx):
+    """Jobs of the size of the roots of configs 3-5 with heavy-tailed edge lengths: dozens of MODE 2 bands with long column
+    entries, remote row entries and overflow columns in flight at once (tools/probe_big.py goes to 6000 x 5000)."""
+    from prographmsa_amd import jobs as J
+    js = [J.random_job(77, 2300, 2200, skip_frac=0.3, skip_span=150, skip_max=5),
+          J.random_job(78, 1500, 2600, skip_frac=0.5, skip_span=27, skip_max=14),
+          J.random_job(79, 2600, 1400, skip_frac=0.25, skip_span=90, skip_max=6, repeat_frac=0.03, repeat_span=120)]
+    b = J.Batch(ctx, js)
+    b.run()
+    res = b.fetch()
+    for i, j in enumerate(js):
+        _cmp_job(b, i, j, res[i])
+    b.close()
+
+
 def test_one_call_entry_point(ctx):
     import oracle_lib
     from prographmsa_amd import jobs as J

@@ -14,6 +14,10 @@ cases = [
     ("light 1030x1020 x8", [dict(n1=1030, n2=1020, skip_frac=0.03, skip_span=4)] * 8),
     ("heavy 2100x2150 x2", [dict(n1=2100, n2=2150, skip_frac=0.5, skip_span=14, skip_max=3)] * 2),
     ("chain 300x2000 x64", [dict(n1=300, n2=2000, skip_frac=0.0, drop_chain_frac=0.0)] * 64),
+    # heavy-tailed graphs at the size of the roots of configs 4 / 5 and beyond (MODE 2 with long / remote entries, overflow table)
+    ("tails 3700x3600 x1", [dict(n1=3700, n2=3600, skip_frac=0.3, skip_span=150, skip_max=5)]),
+    ("dense 2500x2600 x2", [dict(n1=2500, n2=2600, skip_frac=0.5, skip_span=27, skip_max=14)] * 2),
+    ("mixed 6000x5000 x1", [dict(n1=6000, n2=5000, skip_frac=0.25, skip_span=90, skip_max=6, repeat_frac=0.03, repeat_span=120)]),
 ]
 for name, specs in cases:
     js = [J.random_job(500 + i, sp["n1"], sp["n2"], **{k: v for k, v in sp.items() if k not in ("n1", "n2")}) for i, sp in enumerate(specs)]
