@@ -1308,10 +1308,21 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             Y_o = Yv;
             ow[s0] = Wv;
             ox[s0] = Xv;
+            if (HELPED && i == BL / 2 - 1 && has_next && !stall) {
+                // a band on the critical path publishes its progress twice per block (the band below follows 4 steps closer):
+                // all but the last 4 stores — i.e. every step before this block — are complete
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL / 2) : "memory");
+                if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (has_next && !stall) {
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
-            if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (HELPED) {   // (the word store above is one of the last BL / 2 + 1 memory operations)
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL / 2 + 1) : "memory");
+                if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0 + BL / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL) : "memory");
+                if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // Stage the next blocks.  This sits at the END of the iteration so that, on every path into it, exactly the BL
         // cell stores of this block were issued after the prefetch loads consumed here: the compiler then waits for them
