@@ -1084,15 +1084,14 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 #pragma unroll
     for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
     load_s_block(BL);
-    wait_prev(BL + 64 + BL);
+    wait_prev(HELPED ? BL + 64 : BL + 64 + BL);   // (HELPED: the virtual lanes of block 1 are requested in the middle of block 0)
     if (has_prev) {
         if (D >= (uint32_t)(VL + BL)) { load_rep_block(-2 * BL); store_rep_block(-2 * BL); }
         load_rep_block(-BL); store_rep_block(-BL);
         load_rep_block(0); store_rep_block(0);
     }
     load_ring_block(2 * BL);
-    load_rep_block(BL);
-    poll_issue();
+    if (!HELPED) { load_rep_block(BL); poll_issue(); }
     if (HELPED) {   // history initialised, first blocks staged: the helpers may start (sw[0] = last recorded step + 2)
         for (int i = lane; i < 4 * 192; i += 64) res[i] = PGM_NEG_INF;
         if (lane >= 1 && lane < PGM_WAVES && !(hmask & (1u << lane))) sw[lane] = 0x7fffffff;   // wavefronts that publish nothing for this item
@@ -1314,9 +1313,17 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL / 2) : "memory");
                 if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (HELPED && i == BL / 2 - 1) {
+                // ... and asks for the virtual lanes of the next block only now, half a block before they are stored into the history
+                // (their loads still have four steps to complete): it follows the band above another 3-4 steps closer
+                poll_collect();
+                wait_prev(t0 + BL + BL + 64);
+                load_rep_block((int)(t0 + BL));
+                poll_issue();
+            }
         }
         if (has_next && !stall) {
-            if (HELPED) {   // (the word store above is one of the last BL / 2 + 1 memory operations)
+            if (HELPED) {   // (since the first four stores of the block: the word store, two virtual-lane loads, the poll, four cell stores)
                 asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BL / 2 + 1) : "memory");
                 if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0 + BL / 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
@@ -1337,10 +1344,12 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
         store_rep_block((int)t1);
         load_ring_block(t1 + 2 * BL);
         load_s_block(t1 + BL);
-        poll_collect();
-        wait_prev(t1 + BL + BL + 64);
-        load_rep_block((int)(t1 + BL));
-        poll_issue();
+        if (!HELPED) {
+            poll_collect();
+            wait_prev(t1 + BL + BL + 64);
+            load_rep_block((int)(t1 + BL));
+            poll_issue();
+        }
     }
     if (HELPED) __hip_atomic_store(sw, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the helpers (also after an abort)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
