@@ -1051,6 +1051,20 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
             hY[idx] = pfr[u].y;
         }
     };
+    // HELPED: the same in half blocks of four steps, one entry per lane (requested four steps before use: see the sweep)
+    auto load_rep_half = [&](int s0) {
+        const int s = s0 + lane / VL, v = lane % VL;
+        const int col = s + (VL - v);
+        float2 val = make_float2(PGM_NEG_INF, PGM_NEG_INF);
+        if (has_prev && col >= 0 && col < (int)ncol) val = pgm_gload_cell_wy(cells_prev + (size_t)(s + 64) * 64u + (uint32_t)(64 - VL + v));
+        pfr[0] = val;
+    };
+    auto store_rep_half = [&](int s0) {
+        const int s = s0 + lane / VL, v = lane % VL;
+        const uint32_t idx = ((uint32_t)s & Dm) * HS + (uint32_t)v;
+        hW[idx] = pfr[0].x;
+        hY[idx] = pfr[0].y;
+    };
     int seen = has_prev ? 0 : 0x7fffffff, pend = 0;
     auto wait_prev = [&](uint32_t steps_needed) {   // band b-1 has completed (and made visible) that many steps
         if (seen != 0x7fffffff && !aborted) {
@@ -1084,14 +1098,16 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 #pragma unroll
     for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
     load_s_block(BL);
-    wait_prev(HELPED ? BL + 64 : BL + 64 + BL);   // (HELPED: the virtual lanes of block 1 are requested in the middle of block 0)
+    wait_prev(HELPED ? BL + 64 : BL + 64 + BL);   // (HELPED: virtual lanes in half blocks, stored just in time: steps 0-3 now, 4-7 requested)
     if (has_prev) {
         if (D >= (uint32_t)(VL + BL)) { load_rep_block(-2 * BL); store_rep_block(-2 * BL); }
         load_rep_block(-BL); store_rep_block(-BL);
-        load_rep_block(0); store_rep_block(0);
+        if (HELPED) { load_rep_half(0); store_rep_half(0); }
+        else { load_rep_block(0); store_rep_block(0); }
     }
     load_ring_block(2 * BL);
-    if (!HELPED) { load_rep_block(BL); poll_issue(); }
+    if (HELPED) load_rep_half(BL / 2); else load_rep_block(BL);
+    poll_issue();
     if (HELPED) {   // history initialised, first blocks staged: the helpers may start (sw[0] = last recorded step + 2)
         for (int i = lane; i < 4 * 192; i += 64) res[i] = PGM_NEG_INF;
         if (lane >= 1 && lane < PGM_WAVES && !(hmask & (1u << lane))) sw[lane] = 0x7fffffff;   // wavefronts that publish nothing for this item
@@ -1314,11 +1330,13 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
                 if (lane == 0) __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)&J.prog[b], (int)t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (HELPED && i == BL / 2 - 1) {
-                // ... and asks for the virtual lanes of the next block only now, half a block before they are stored into the history
-                // (their loads still have four steps to complete): it follows the band above another 3-4 steps closer
+                // ... and handles the virtual lanes in half blocks: the four steps ahead are stored into the history now (their loads
+                // had four steps to complete), the four after them are requested: the band needs the one above 72 steps ahead of
+                // its next step, not 80 ahead of its next block
+                store_rep_half((int)(t0 + BL / 2));
                 poll_collect();
-                wait_prev(t0 + BL + BL + 64);
-                load_rep_block((int)(t0 + BL));
+                wait_prev(t0 + BL + 64 + BL / 2);
+                load_rep_half((int)(t0 + BL));
                 poll_issue();
             }
         }
@@ -1341,15 +1359,18 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
         store_ring_block(t1 + BL);     // one block before use
 #pragma unroll
         for (int q = 0; q < BL / 4; ++q) { Sc[4 * q] = pfs[q].x; Sc[4 * q + 1] = pfs[q].y; Sc[4 * q + 2] = pfs[q].z; Sc[4 * q + 3] = pfs[q].w; }
-        store_rep_block((int)t1);
+        if (HELPED) store_rep_half((int)t1); else store_rep_block((int)t1);
         load_ring_block(t1 + 2 * BL);
         load_s_block(t1 + BL);
-        if (!HELPED) {
-            poll_collect();
+        poll_collect();
+        if (HELPED) {
+            wait_prev(t1 + BL + 64);
+            load_rep_half((int)(t1 + BL / 2));
+        } else {
             wait_prev(t1 + BL + BL + 64);
             load_rep_block((int)(t1 + BL));
-            poll_issue();
         }
+        poll_issue();
     }
     if (HELPED) __hip_atomic_store(sw, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the helpers (also after an abort)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
