@@ -1494,7 +1494,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
         const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         const int totL = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         ne = min(totR + totL, 512);   // (the host keeps a band within 512 entries and PGM_REMOTE_MAX remote ones)
-        single = !LONG && ne <= 64;
+        single = ne <= 64;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
             const int idx = (int)p_of(q) * 64 + lane;
@@ -1509,7 +1509,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     }
     const bool do_near = !single || part == 0u, do_pairs = !single || part >= 1u;
     const uint32_t pj0 = single ? part - 1u : 0u, pjs = single ? 2u : 1u;   // this wavefront's far column entries: j = pj0, pj0 + pjs, ...
-    if (GROUP == 2 && !LONG && (int)p_of(0) * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
+    if (GROUP == 2 && (int)p_of(0) * 64 >= ne) {   // no pass of the entry list for this wavefront: nothing to publish but "done"
         __hip_atomic_store(sw + hidx, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
     }
@@ -1692,7 +1692,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                 // ---- row entries, one entry per lane; this wavefront's passes: p = part + nparts q ----
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) {
-                    const bool fifo = LONG && q == 0;   // (the first pass keeps its FIFO moving even without entries)
+                    const bool fifo = LONG && q == 0;   // (the first pass keeps its FIFO moving even without remote entries or near part: counted waits)
                     if ((int)p_of(q) * 64 < ne || fifo) {
                         const uint32_t o = e_o[q], dy = e_dy[q];
                         const float cy = e_cy[q];
@@ -1701,7 +1701,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                         const float4 cno = ring3[rso];
                         const float So = sblk[i * 64 + (int)o];
                         const float gopen_y = (xo == 0) ? sg : gi;
-                        const bool rem = fifo && e_rem;
+                        const bool rem = LONG && q == 0 && e_rem;
                         const uint32_t s1 = t - dy, lp = rem ? 0u : (uint32_t)VL + o - dy;
                         float Yh = PGM_NEG_INF, Wh = PGM_NEG_INF, W1 = PGM_NEG_INF, W2 = PGM_NEG_INF, W3 = PGM_NEG_INF;
                         if (do_near) {
@@ -1713,7 +1713,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             const bool cv = rem && (uint32_t)xo < ncol;
                             const float Wr = cv ? cur.x : PGM_NEG_INF;
                             rw[s0] = Wr;
-                            if (rem) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[sm1]; W2 = rw[sm2]; W3 = rw[sm3]; }
+                            if (rem && do_near) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[sm1]; W2 = rw[sm2]; W3 = rw[sm3]; }
                             issue2(xo + PF, s0);
                         }
                         const float Yt = __fsub_rn(fmaxf(__fadd_rn(Yh, ge), __fadd_rn(Wh, gopen_y)), cy);   // (-inf without the near part)
