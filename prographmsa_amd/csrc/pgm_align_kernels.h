@@ -1430,6 +1430,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     uint2 *elist = (uint2 *)(aux + PGM_AUX_EL);
     int *ecnt = (int *)(aux + PGM_AUX_CNT);
     uint2 *ovtab = (uint2 *)(slot + J.ov_off);
+    float *rh = (float *)(slot + J.rh_off) + part * 2048u;   // GROUP 2, LONG: W of the last 32 columns of this wavefront's remote rows [column & 31][lane]
     const bool has_ov = GROUP != 0 && J.nov2 != 0;
     const int slack = GROUP == 0 ? (part == 0u ? 3 : 4) : (int)J.far_slack;
     const uint32_t y = 64u * b + (uint32_t)lane;
@@ -1553,6 +1554,8 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     if (LONG && GROUP == 2) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) rw[k] = PGM_NEG_INF;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) rh[k * 64 + lane] = PGM_NEG_INF;
     }
     if (LONG && GROUP == 1) {
 #pragma unroll
@@ -1713,6 +1716,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                             const bool cv = rem && (uint32_t)xo < ncol;
                             const float Wr = cv ? cur.x : PGM_NEG_INF;
                             rw[s0] = Wr;
+                            if (rem) rh[((uint32_t)xo & 31u) * 64u + (uint32_t)lane] = Wr;   // (pairs with the far edges of later columns read it back)
                             if (rem && do_near) { Yh = cv ? cur.y : PGM_NEG_INF; Wh = Wr; W1 = rw[sm1]; W2 = rw[sm2]; W3 = rw[sm3]; }
                             issue2(xo + PF, s0);
                         }
@@ -1733,45 +1737,46 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 #pragma unroll
                             for (int j = 0; j < KF; ++j) {
                                 if (j < nw && (pjs == 1u || ((uint32_t)j & 1u) == pj0)) {
-                                    const bool on = !LONG || ((uint32_t)j < nfo && !rem);
-                                    const float Wp = hW[((s1 - (on ? gdx[j] : 1u)) & Dm) * HS + lp];
+                                    const bool on = !LONG || (uint32_t)j < nfo;
+                                    float Wp = hW[((s1 - (on ? gdx[j] : 1u)) & Dm) * HS + lp];
+                                    if (LONG) {   // a remote row: W of its source row at that column comes from the ring of its own walk
+                                        const int colp = xo - (int)(on ? gdx[j] : 1u);
+                                        const float Wr2 = rh[((uint32_t)colp & 31u) * 64u + (uint32_t)lane];
+                                        if (rem) Wp = colp >= 0 ? Wr2 : PGM_NEG_INF;
+                                    }
                                     Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), on ? gcx[j] : INFINITY));
                                 }
                             }
                             const uint32_t ovi = PGM_NF_OVI(fow) * (uint32_t)PGM_OV_ENT;
                             if (has_ov) {
-                                for (uint32_t j = pj0; __builtin_amdgcn_ballot_w64(j < novo && !rem) != 0ull; j += pjs) {
-                                    const bool on = j < novo && !rem;
+                                for (uint32_t j = pj0; __builtin_amdgcn_ballot_w64(j < novo) != 0ull; j += pjs) {
+                                    const bool on = j < novo;
                                     const uint2 e = ovtab[on ? ovi + j : 0u];
-                                    const float Wp = hW[((s1 - (on ? e.x : 1u)) & Dm) * HS + lp];
+                                    float Wp = hW[((s1 - (on ? e.x : 1u)) & Dm) * HS + lp];
+                                    if (LONG) {
+                                        const int colp = xo - (int)(on ? e.x : 1u);
+                                        const float Wr2 = rh[((uint32_t)colp & 31u) * 64u + (uint32_t)lane];
+                                        if (rem) Wp = colp >= 0 ? Wr2 : PGM_NEG_INF;
+                                    }
                                     Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(Wp, So), cy), on ? __uint_as_float(e.y) : INFINITY));
                                 }
                             }
                             if (LONG) {
-                                // pairs the history does not hold — (remote row, far column), (any far row, long column) — on demand:
-                                // the loads of the eight slots together, then the overflow entries of a remote row one by one
-                                const bool dem = (rem && (nfo | novo) != 0u) || nlo != 0u;
+                                // pairs neither the history nor the remote rows' rings hold — (any far row, long column) — on demand: the
+                                // loads of the slots together
+                                const bool dem = nlo != 0u && pj0 == 0u;   // (one of the wavefronts that share a pass)
                                 if (__builtin_amdgcn_ballot_w64(dem) != 0ull) {
                                     const uint32_t sb = rem ? e_off : row_off(64u * b + o - dy);
-                                    float Wq[KF];
-                                    bool onq[KF];
+                                    float Wq[NL];
+                                    bool onq[NL];
 #pragma unroll
-                                    for (int j = 0; j < KF; ++j) {
-                                        const int col = xo - (int)gdx[j];
-                                        onq[j] = ((rem && (uint32_t)j < nfo) || (uint32_t)j >= (uint32_t)KF - nlo) && col >= 0;
-                                        Wq[j] = load_w(onq[j] ? sb + (uint32_t)col * 1024u : 0u);
+                                    for (int u = 0; u < NL; ++u) {
+                                        const int j = KF - 1 - u, col = xo - (int)gdx[j];
+                                        onq[u] = dem && (uint32_t)u < nlo && col >= 0;
+                                        Wq[u] = load_w(onq[u] ? sb + (uint32_t)col * 1024u : 0u);
                                     }
 #pragma unroll
-                                    for (int j = 0; j < KF; ++j) Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(onq[j] ? Wq[j] : PGM_NEG_INF, So), cy), gcx[j]));
-                                    if (has_ov) {
-                                        for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(rem && j < novo) != 0ull; ++j) {
-                                            const bool on = rem && j < novo;
-                                            const uint2 e = ovtab[on ? ovi + j : 0u];
-                                            const int col = xo - (int)e.x;
-                                            const float Wp = load_w((on && col >= 0) ? sb + (uint32_t)col * 1024u : 0u);
-                                            Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn((on && col >= 0) ? Wp : PGM_NEG_INF, So), cy), on ? __uint_as_float(e.y) : INFINITY));
-                                        }
-                                    }
+                                    for (int u = 0; u < NL; ++u) Mt = fmaxf(Mt, __fsub_rn(__fsub_rn(__fadd_rn(onq[u] ? Wq[u] : PGM_NEG_INF, So), cy), gcx[KF - 1 - u]));
                                 }
                             }
                         }

@@ -39,7 +39,7 @@
 //          bits 16-17: number of LONG entries (distance > PGM_DCAP; slots 7, 6, 5), served from the cell storage by the far
 //                    helper (the count of bits 0-3 then covers the slots before them)
 //          bits 20-24: number of OVERFLOW entries (on-chip entries beyond the slots of the summary, at most PGM_OV_ENT), kept in
-//                    record (bits 25-30) of the job's overflow table (PgmJob::ov2, copied to LDS by the far helpers)
+//                    record (bits 25-31) of the job's overflow table (PgmJob::ov2, copied to LDS by the far helpers)
 //   fd_k   (node - predecessor) of far edge k, 0 if absent;   fc_k its cost, +inf if absent
 // In a MODE 2 job the far entries of the ROWS are not taken from here but from the CSR PgmJob::fp1 / fe1 (any number per
 // row; an entry farther than PGM_DCAP or reaching above the band's virtual lanes is REMOTE: served from the cell storage).
@@ -49,9 +49,9 @@
 #define PGM_NF_KILL 32u
 #define PGM_NF_NLONG(f) (((f) >> 16) & 3u)
 #define PGM_NF_NOV(f) (((f) >> 20) & 31u)
-#define PGM_NF_OVI(f) (((f) >> 25) & 63u)
+#define PGM_NF_OVI(f) (((f) >> 25) & 127u)
 #define PGM_OV_ENT 16      /* overflow entries per record */
-#define PGM_OV_REC 48      /* records per job (6 KB of LDS) */
+#define PGM_OV_REC 128     /* records per job (16 KB of LDS) */
 #define PGM_NLONG 3        /* long entries per column */
 struct PgmNode2 {
     float cc, c2, c3;
@@ -114,6 +114,7 @@ struct PgmJob {
     const uint2 *fe1;
     const uint2 *ov2;                // mode2: overflow table of the columns, nov2 records of PGM_OV_ENT {distance, cost bits}
     uint32_t nov2, ov_off;           // records in use; offset of the table's copy inside a sweep's LDS slot
+    uint32_t rh_off, lw_off;         // LONG jobs: offsets of the remote rows' W rings [3 parts][32][64] and of the long slots' W history [3][32][64]
     // full predecessor lists in PredIterator order (regular ascending, then repeats) for the traceback
     const int32_t *pp1, *pp2;
     const uint32_t *pc1, *pc2;
