@@ -553,12 +553,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 J.has_far = (o.s1.far_nodes + o.s2.far_nodes) > 0 ? 1u : 0u;
                 J.long1 = (J.mode2 && o.s1.remote) ? 1u : 0u;
                 J.long2 = (J.mode2 && o.s2.remote) ? 1u : 0u;
-                J.rh_off = J.slot_bytes; J.lw_off = J.slot_bytes;
-                if (J.long1 | J.long2) {   // W of the last 32 columns of every remote row's walk, own-row W of the last 32 steps of every long slot
-                    J.slot_bytes += 3u * 32u * 64u * 4u;
-                    J.lw_off = J.slot_bytes;
-                    J.slot_bytes += 3u * 32u * 64u * 4u;
-                }
+                J.rh_off = J.slot_bytes;
+                if (J.long1 | J.long2) J.slot_bytes += 3u * 32u * 64u * 4u;   // W of the last 32 columns of every remote row's walk (one ring per row helper)
                 J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.nslots = J.mode2 ? 1u : std::max(1u, std::min((uint32_t)PGM_WAVES, (uint32_t)PGM_POOL / J.slot_bytes));
                 if (job_stats) {   // tools: how the nodes of this job are served

@@ -114,7 +114,7 @@ struct PgmJob {
     const uint2 *fe1;
     const uint2 *ov2;                // mode2: overflow table of the columns, nov2 records of PGM_OV_ENT {distance, cost bits}
     uint32_t nov2, ov_off;           // records in use; offset of the table's copy inside a sweep's LDS slot
-    uint32_t rh_off, lw_off;         // LONG jobs: offsets of the remote rows' W rings [3 parts][32][64] and of the long slots' W history [3][32][64]
+    uint32_t rh_off;                 // LONG jobs: offset of the remote rows' W rings [3 row helpers][column & 31][lane]
     // full predecessor lists in PredIterator order (regular ascending, then repeats) for the traceback
     const int32_t *pp1, *pp2;
     const uint32_t *pc1, *pc2;
