@@ -907,7 +907,16 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         J.hmap1[i] = J.map1[j];
         J.hmap2[i] = J.map2[j];
     }
-    if (tid == 0) *J.hresult = *J.result;
+    // the record announces the mappings to a host that copies finished jobs while the kernel is still running
+    // (pgm_align_batch_fetch polls `status`): mappings first, then score / counts / length, the status word last
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const PgmJob::Result r = *J.result;
+        J.hresult->score = r.score; J.hresult->n_tr_indels = r.n_tr_indels; J.hresult->len = r.len;
+        __threadfence_system();
+        __hip_atomic_store(&J.hresult->status, r.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 #define PGM_SPIN_LIMIT (1u << 24)
@@ -1866,7 +1875,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             __syncthreads();
             if (threadIdx.x == 0) {
                 const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; *J.hresult = *J.result; }
+                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
                 tb_go = ok ? 1 : 0;
             }
             __syncthreads();

@@ -390,9 +390,11 @@ static hipError_t scratch_events(pgm_ctx *ctx) {
     return hipSuccess;
 }
 
+#define PGM_STATUS_PENDING 0x7ffffff0   /* status word of a job's result record in the pinned block until its traceback worker has written it */
 static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipStream_t s = ctx->stream;
     hipError_t e;
+    for (uint32_t i = 0; i < b->njobs; ++i) ((PgmJob::Result *)(b->h_out + b->res_off[i]))->status = PGM_STATUS_PENDING;
     if (timed && (e = hipEventRecord(b->ev[0], s)) != hipSuccess) return e;
     if (b->maxdim <= 20) {
         const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim + 256 * ((size_t)b->maxdim + 1)) * sizeof(float);
@@ -777,6 +779,37 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     if (getenv("PGM_FILL_DBG"))   // instrumented kernel variants leave their counters in the device block
         HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(b->h_flag, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // Finished jobs are copied out while the kernel is still running: a job's traceback worker writes the reversed mappings
+    // and then the result record (status word last) into the pinned block; all but the largest jobs are done long before the
+    // batch is, so only a few records are left when the stream completes.
+    std::vector<uint8_t> copied(b->njobs, 0);
+    auto collect = [&]() -> int {
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < b->njobs; ++i) {
+            if (copied[i]) { ++n; continue; }
+            const PgmJob::Result *hr = (const PgmJob::Result *)(b->h_out + b->res_off[i]);
+            const int32_t st = __atomic_load_n(&hr->status, __ATOMIC_ACQUIRE);
+            if (st == PGM_STATUS_PENDING) continue;
+            if (!out[i].map1 || !out[i].map2) return -1;
+            const uint32_t len = hr->len;
+            if (len > b->jobs[i].n1 + b->jobs[i].n2) return -2;
+            out[i].score = hr->score; out[i].n_tr_indels = hr->n_tr_indels; out[i].len = len; out[i].status = st;
+            memcpy(out[i].map1, b->h_out + b->map1_off[i], 4 * (size_t)len);
+            memcpy(out[i].map2, b->h_out + b->map2_off[i], 4 * (size_t)len);
+            copied[i] = 1; ++n;
+        }
+        return (int)n;
+    };
+    if (!getenv("PGM_FILL_DBG") && !b->d_trace) {
+        for (;;) {
+            const int n = collect();
+            if (n < 0) { (void)hipStreamSynchronize(ctx->stream); return fail(n == -1 ? PGM_ERR_INVALID : PGM_ERR_DEVICE, n == -1 ? "null mapping buffer" : "corrupt result length"); }
+            if ((uint32_t)n == b->njobs) break;
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) break;                       // (an aborted launch leaves records pending)
+            if (q != hipErrorNotReady) return fail(PGM_ERR_DEVICE, std::string("fill kernel: ") + hipGetErrorString(q));
+        }
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int aborted = *b->h_flag;
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
@@ -793,6 +826,9 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     for (uint32_t i = 0; i < b->njobs; ++i) {
         PgmJob::Result res;
         memcpy(&res, b->h_out + b->res_off[i], sizeof res);
+        if (res.status == PGM_STATUS_PENDING && !getenv("PGM_FILL_DBG")) return fail(PGM_ERR_DEVICE, "fill kernel: a job's result record was never written");
+        if (res.status != PGM_OK) rc = res.status;
+        if (copied[i]) continue;
         out[i].score = res.score;
         out[i].n_tr_indels = res.n_tr_indels;
         out[i].len = res.len;
