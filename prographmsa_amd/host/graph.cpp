@@ -33,6 +33,29 @@ Graph::Graph(int dim, const std::vector<std::vector<double>> &nodes, const EdgeM
     setRepeatsFromMap(repeats);
 }
 
+Graph::Graph(int dim, index_t n, const double *profiles, const std::vector<EdgeRec> &edges, const std::vector<RepeatRec> &repeats)
+    : dim_(dim), n_(n) {
+    sites_.assign((size_t)dim * n_, 0.0);
+    if (n_ > 2) std::copy(profiles + dim, profiles + (size_t)dim * (n_ - 1), sites_.begin() + dim);
+    e_rowptr_.assign(n_ + 1, 0);
+    e_col_.resize(edges.size());
+    e_val_.resize(edges.size());
+    for (size_t k = 0; k < edges.size(); ++k) {
+        e_rowptr_[edges[k].to + 1]++;
+        e_col_[k] = edges[k].from;
+        e_val_[k] = std::min(edges[k].cost, MAX_EDGE_COST) - MAX_EDGE_COST;  // Graph.h:85
+    }
+    r_rowptr_.assign(n_ + 1, 0);
+    r_col_.resize(repeats.size());
+    r_units_.resize(repeats.size());
+    for (size_t k = 0; k < repeats.size(); ++k) {
+        r_rowptr_[repeats[k].to + 1]++;
+        r_col_[k] = repeats[k].from;
+        r_units_[k] = repeats[k].units;
+    }
+    for (index_t i = 0; i < n_; ++i) { e_rowptr_[i + 1] += e_rowptr_[i]; r_rowptr_[i + 1] += r_rowptr_[i]; }
+}
+
 void Graph::fillInitialEdges() {  // chain edges (i+1 <- i) with stored value -MAX_EDGE_COST (cost 0)
     e_rowptr_.assign(n_ + 1, 0);
     e_col_.clear();

@@ -161,14 +161,6 @@ AlignmentResult alignGraphs(const Graph &g1, const Graph &g2, const Model &model
 }
 
 // ---------------------------------------------------------------------------------------
-template <class MAP, class V>
-static inline void updateEdge(MAP &map, index_t from, index_t to, V cost) {  // GraphAlign.h:539-548
-    std::pair<index_t, index_t> i(to, from);
-    auto it = map.find(i);
-    if (it != map.end()) it->second = std::min(it->second, cost);
-    else map[i] = cost;
-}
-
 // y = P * g(:,i), P column-major
 // Association follows Eigen 3.0-3.2's column-major gemv (four columns at a time,
 // res += (c0 v0 + c1 v1) + (c2 v2 + c3 v3), leftover columns one by one): the binary's Eigen
@@ -252,14 +244,19 @@ AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &p
     result.mapping1 = plan.mapping1;
     result.mapping2 = plan.mapping2;
     result.is_matched = plan.is_matched;
-    std::vector<std::vector<double>> nodes(plan.mapping1.size());
-    for (size_t v = 0; v < nodes.size(); ++v) nodes[v].assign(profiles.begin() + (size_t)D * v, profiles.begin() + (size_t)D * (v + 1));
-    Graph::EdgeMap edges;
-    Graph::RepeatMap repeats;
+    // The reference collects the merged graph's edges in two ordered maps keyed (to, from), an existing edge keeping the smaller
+    // cost (updateEdge, GraphAlign.h:539-548).  Here they are appended to flat lists, sorted by the same key and reduced with the
+    // same minimum: the same set of (key, cost) in the same order, without a tree node per edge.
+    const size_t nnodes = plan.mapping1.size();
+    std::vector<Graph::EdgeRec> edges;
+    std::vector<Graph::RepeatRec> repeats;
+    edges.reserve(3 * nnodes);
+    auto updateEdge = [](std::vector<Graph::EdgeRec> &l, index_t from, index_t to, dp_score_t cost) { l.push_back(Graph::EdgeRec{to, from, cost}); };
+    auto updateRepeat = [](std::vector<Graph::RepeatRec> &l, index_t from, index_t to, index_t units) { l.push_back(Graph::RepeatRec{to, from, units}); };
 
     /* homologous path (GraphAlign.h:626-657) */
     index_t last_xy = 0, last_x = 0, last_y = 0, last_mapped = 0;
-    for (index_t i = 1; i < nodes.size(); ++i) {
+    for (index_t i = 1; i < nnodes; ++i) {
         if (!result.is_matched[i]) continue;
         updateEdge(edges, last_mapped, i, (dp_score_t)0);
         last_mapped = i;
@@ -305,12 +302,24 @@ AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &p
                     else if (result.is_matched[*from] || result.is_matched[to]) updateEdge(edges, y, x, (dp_score_t)(from.value() + pen / 2));
                     else updateEdge(edges, y, x, from.value());
                 } else {
-                    updateEdge(repeats, y, x, from.repeatUnits());
+                    updateRepeat(repeats, y, x, from.repeatUnits());
                 }
             }
         }
     }
-    result.graph = Graph(D, nodes, edges, repeats);
+    {
+        std::sort(edges.begin(), edges.end(), [](const Graph::EdgeRec &a, const Graph::EdgeRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.cost < c.cost); });
+        size_t w = 0;
+        for (size_t k = 0; k < edges.size(); ++k)   // the cheapest of equal keys comes first
+            if (w == 0 || edges[w - 1].to != edges[k].to || edges[w - 1].from != edges[k].from) edges[w++] = edges[k];
+        edges.resize(w);
+        std::sort(repeats.begin(), repeats.end(), [](const Graph::RepeatRec &a, const Graph::RepeatRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.units < c.units); });
+        w = 0;
+        for (size_t k = 0; k < repeats.size(); ++k)
+            if (w == 0 || repeats[w - 1].to != repeats[k].to || repeats[w - 1].from != repeats[k].from) repeats[w++] = repeats[k];
+        repeats.resize(w);
+    }
+    result.graph = Graph(D, (index_t)nnodes, profiles.data(), edges, repeats);
     return result;
 }
 

@@ -130,6 +130,11 @@ public:
     Graph(int dim, const std::vector<std::vector<double>> &nodes);              // :104-120
     Graph(int dim, const std::vector<std::vector<double>> &nodes, const EdgeMap &edges,
           const RepeatMap &repeats);                                            // :122-139
+    // the same from flat data (mergeGraphs' hot path): profiles dim x n column-major (columns 0 and n - 1 are taken as zero),
+    // edge / repeat lists sorted by (to, from) without duplicates — what iterating the two maps above yields
+    struct EdgeRec { index_t to, from; dp_score_t cost; };
+    struct RepeatRec { index_t to, from, units; };
+    Graph(int dim, index_t n, const double *profiles, const std::vector<EdgeRec> &edges, const std::vector<RepeatRec> &repeats);
 
     index_t size() const { return n_; }
     int dim() const { return dim_; }
