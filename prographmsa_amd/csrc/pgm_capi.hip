@@ -653,7 +653,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     std::stable_sort(b->order.begin(), b->order.end(), [&](uint32_t x, uint32_t y) {
         return (uint64_t)b->jobs[x].n1 * b->jobs[x].n2 > (uint64_t)b->jobs[y].n1 * b->jobs[y].n2;
     });
-    // ---- fill work list.  An item is a band (merged graphs) or a group of four bands (chain-only jobs); item k of a job
+    // ---- fill work list.  An item is a band (MODE 2 jobs) or a group of up to eight bands (all others); item k of a job
     // can start once item k-1 has been running for the band-to-band lag, and the workers take items in list order.  The
     // order is the result of simulating the persistent workers on the host with estimated times: whenever a worker is
     // free it takes, among the items that are READY by then, the one with the longest remaining path (the time until its

@@ -91,12 +91,12 @@ struct PgmJob {
     uint32_t maxn;         // max(n1,n2)
     uint32_t has_extras;   // some node of either graph has a predecessor other than its chain neighbour
     uint32_t has_far;      // some node has a predecessor served from the LDS history (the sweeps then record W, Y, X there)
-    uint32_t mode2;        // one band per worker: the other three wavefronts evaluate every term but the two chain terms (nslots = 1)
-    uint32_t far_slack;    // min(4, smallest far distance): the far helper may evaluate step t once step t - far_slack is recorded
+    uint32_t mode2;        // one band per worker: its other seven wavefronts evaluate every term the sweep does not hold in registers (nslots = 1)
+    uint32_t far_slack;    // min(4, smallest far distance): the far helpers may evaluate step t once step t - far_slack is recorded (4: the depth of the folded maxima)
     uint32_t aux_off;      // offset of the helper area (PGM_AUX_*) inside a sweep's LDS slot
     uint32_t hD, hDX;      // depth (steps, power of two) of the W / Y history and of the X history of a sweeping wavefront
     uint32_t slot_bytes;   // LDS bytes one sweeping wavefront needs for this job (history + column rings)
-    uint32_t nslots;       // bands of this job one worker sweeps at a time = min(4, PGM_POOL / slot_bytes)
+    uint32_t nslots;       // bands of this job one worker sweeps at a time = min(8, PGM_POOL / slot_bytes)
     uint32_t long1, long2; // mode2 only: graph 1 has REMOTE row entries / graph 2 has LONG column entries (served from the cell
                            // storage by the far helpers: farther than PGM_DCAP, or reaching above the band's virtual lanes)
     pgm_scores sc;
@@ -150,7 +150,7 @@ struct PgmJob {
 
 
 // One unit of fill work: `count` consecutive bands (64 rows each) of job `job`, starting at `band`, one per wavefront of
-// the worker that takes the item (count <= PgmJob::nslots <= 4).  The list is ordered so that a job's bands come in
+// the worker that takes the item (count <= PgmJob::nslots <= 8; a MODE 2 job: one band, swept with seven helper wavefronts).  The list is ordered so that a job's bands come in
 // ascending order (workers take the items in list order, see pgm_fill_kernel).
 struct PgmItem {
     uint32_t job, band;
