@@ -73,6 +73,26 @@ def test_large_heavy_tailed_jobs_bit_exact(ctx):
     b.close()
 
 
+def test_relaunch_and_fetch(ctx):
+    """run, run, fetch and run, fetch, fetch: the result records in the pinned block are reset by every launch and copied
+    out by fetch while the kernel is still running (status word last); every fetch returns the same results."""
+    from prographmsa_amd import jobs as J
+    js = [J.random_job(300 + i, 260 + 37 * i, 300 - 11 * i, skip_frac=0.2) for i in range(12)]
+    b = J.Batch(ctx, js)
+    b.run(); b.run()
+    r1 = b.fetch()
+    b.run()
+    r2 = b.fetch()
+    r3 = b.fetch()
+    for a in (r2, r3):
+        for x, y in zip(r1, a):
+            assert np.array_equal(x["map1"], y["map1"]) and np.array_equal(x["map2"], y["map2"])
+            assert np.float32(x["score"]).view(np.uint32) == np.float32(y["score"]).view(np.uint32) and x["status"] == y["status"] == 0
+    for i, j in enumerate(js):
+        _cmp_job(b, i, j, r1[i])
+    b.close()
+
+
 def test_one_call_entry_point(ctx):
     import oracle_lib
     from prographmsa_amd import jobs as J
