@@ -499,10 +499,40 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         sync_ints += (J.nb + 3) / 4 * 4;
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
-    // pass 2 (host threads): flatten every job straight into a pinned staging buffer (kept by the context)
+    // The device buffers and the pinned result block are allocated (or taken from the context's cache) on a thread of their own
+    // while the jobs are being flattened: all sizes are known after pass 1.
     b->in_bytes = std::max<size_t>(in_base[njobs], 16);
+    b->work_bytes = std::max<size_t>(W.bytes, 16);
+    b->cell_bytes = std::max<size_t>(C.bytes, 16);
+    b->out_bytes = std::max<size_t>(O.bytes, 16);
+    b->s_bytes = std::max<size_t>(SL.bytes, 16);
+    b->sync_ints = sync_ints;
+    hipError_t alloc_err = hipSuccess, alloc_host_err = hipSuccess;
+    uint8_t *h_out_dev = nullptr;
+    std::thread alloc_thread([&]() {
+        hipError_t e2 = hipSetDevice(ctx->device);
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN]);
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK]);
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS]);
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT]);
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S]);
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_sync, sync_ints * sizeof(int));
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs));
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs));
+        alloc_err = e2;
+        // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
+        // into it over PCIe while the kernel is still running
+        if (e2 == hipSuccess) {
+            hipError_t e3 = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST]);
+            if (e3 == hipSuccess) e3 = hipHostMalloc((void **)&b->h_flag, 4 * sizeof(int), hipHostMallocDefault);
+            if (e3 == hipSuccess) e3 = hipHostGetDevicePointer((void **)&h_out_dev, b->h_out, 0);
+            alloc_host_err = e3;
+        }
+    });
+    // pass 2 (host threads): flatten every job straight into a pinned staging buffer (kept by the context)
     hipError_t e;
     if ((e = cache_take(ctx, pgm_ctx::C_HIN, b->in_bytes, (void **)&b->h_in, &b->cap[pgm_ctx::C_HIN])) != hipSuccess) {
+        alloc_thread.join();
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
@@ -592,33 +622,19 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         for (auto &t : pool) t.join();
         if (bad.load() >= 0) {
             const int i = bad.load();
+            alloc_thread.join();
             pgm_align_batch_destroy(ctx, b);
             return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
         }
     }
-    b->work_bytes = std::max<size_t>(W.bytes, 16);
-    b->cell_bytes = std::max<size_t>(C.bytes, 16);
-    b->out_bytes = std::max<size_t>(O.bytes, 16);
-    b->s_bytes = std::max<size_t>(SL.bytes, 16);
-    b->sync_ints = sync_ints;
-    if ((e = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN])) != hipSuccess ||
-        (e = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK])) != hipSuccess ||
-        (e = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS])) != hipSuccess ||
-        (e = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT])) != hipSuccess ||
-        (e = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S])) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_sync, sync_ints * sizeof(int))) != hipSuccess || (e = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs))) != hipSuccess ||
-        (e = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs))) != hipSuccess) {
+    alloc_thread.join();
+    if (alloc_err != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
-        return fail(e == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return fail(alloc_err == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(alloc_err));
     }
-    // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
-    // into it over PCIe while the kernel is still running (fetch is then a stream synchronisation, not a copy)
-    uint8_t *h_out_dev = nullptr;
-    if ((e = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST])) != hipSuccess ||
-        (e = hipHostMalloc((void **)&b->h_flag, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostGetDevicePointer((void **)&h_out_dev, b->h_out, 0)) != hipSuccess) {
+    if (alloc_host_err != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
-        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(alloc_host_err));
     }
     for (uint32_t i = 0; i < njobs; ++i) {
         PgmJob &J = b->jobs[i];
