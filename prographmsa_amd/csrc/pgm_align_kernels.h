@@ -419,14 +419,30 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         constexpr uint32_t NT = 64u * PGM_WAVES;
         constexpr int NC = (int)((TT * TT) / NT), NP = (int)((2 * TT * PGM_TB_PK) / NT);
         static_assert(NC * NT == TT * TT && NP * NT == 2 * TT * PGM_TB_PK, "tile staging: whole rounds of the workgroup");
+        // The cells of one anti-diagonal of the tile (y + x constant) are one contiguous run of the cell storage (same step of the
+        // band, consecutive lanes), the cells of a row are 1 KB apart: the threads therefore take the tile's cells in
+        // anti-diagonal order — position k of diagonal d, the 63 diagonals laid end to end — so that a wavefront's 64 cell loads
+        // touch 8 cache lines instead of 64.  (The scores are laid out in blocks of 8 steps per lane: row order suits them.)
         float4 cv[NC];
         float sv[NC];
+        uint32_t cslot[NC];
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
             const uint32_t i = (uint32_t)tid + NT * u;
-            const uint32_t yy = min(ty0 + i / TT, n1 - 2), xx = min(tx0 + i % TT, n2 - 2);
+            // (d, k) of the i-th cell in anti-diagonal order: the first TT diagonals hold 1, 2, ..., TT cells, the rest mirror them
+            const uint32_t half = TT * (TT + 1u) / 2u;
+            const bool up = i < half;
+            const uint32_t m = up ? i : TT * TT - 1u - i;
+            uint32_t d = (uint32_t)((sqrtf(8.0f * (float)m + 1.0f) - 1.0f) * 0.5f);
+            while (d * (d + 1u) / 2u > m) --d;
+            while ((d + 1u) * (d + 2u) / 2u <= m) ++d;
+            const uint32_t k = m - d * (d + 1u) / 2u;             // 0..d: row k, column d - k of the upper triangle
+            const uint32_t ly = up ? k : TT - 1u - k, lx = up ? d - k : TT - 1u - (d - k);
+            cslot[u] = ly * TT + lx;
+            const uint32_t yy = min(ty0 + ly, n1 - 2), xx = min(tx0 + lx, n2 - 2);
             cv[u] = J.cells[pgm_cell_index(J, yy, xx)];
-            sv[u] = pgm_emission_at(J, yy, xx);
+            const uint32_t ys = min(ty0 + i / TT, n1 - 2), xs = min(tx0 + i % TT, n2 - 2);
+            sv[u] = pgm_emission_at(J, ys, xs);
         }
         // predecessor entries: slot = row (0..TT-1) or column (TT..2TT-1) of the tile, k = entry; straight from the
         // per-node records (same round trip as the cells)
@@ -443,7 +459,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
 #pragma unroll
         for (int u = 0; u < NC; ++u) {
             const uint32_t i = (uint32_t)tid + NT * u;
-            T.cell[i] = cv[u];
+            T.cell[cslot[u]] = cv[u];
             T.S[i] = sv[u];
         }
         for (uint32_t i = (uint32_t)tid; i < 3u * TT * TT / 2u; i += NT) ((uint32_t *)T.succ)[i] = 0u;   // no links yet
