@@ -14,8 +14,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
+#include <sys/mman.h>
 
 #include "pgm_align_kernels.h"
 #include "pgm_nw_kernels.h"
@@ -54,6 +57,49 @@ struct pgm_ctx {
     uint32_t csK = 0, csC = 0;
     double *cs_lprofiles = nullptr, *cs_centre = nullptr, *cs_priors = nullptr;
 };
+
+// ---- pinned host blocks ---------------------------------------------------------------------------
+// hipHostMalloc of the staging block of a 128-job level (76 MB) takes 10-14 ms in a cold process and stalls every other
+// thread that touches the address space meanwhile (hipHostFree: another 8 ms).  A 2 MB aligned block with MADV_HUGEPAGE,
+// first touched by a few threads and registered afterwards, is pinned in ~1 ms (tools/micro/pin_bench.hip: fill 0.9 ms,
+// hipHostRegister 0.2 ms, same copy rate).  Blocks that could not be registered fall back to hipHostMalloc.
+static std::mutex g_pinned_mu;
+static std::unordered_set<void *> g_pinned_registered;
+static hipError_t pinned_alloc(size_t bytes, void **out) {
+    const size_t H = (size_t)2 << 20, len = (std::max<size_t>(bytes, 1) + H - 1) / H * H;
+    void *p = aligned_alloc(H, len);
+    if (p) {
+        (void)madvise(p, len, MADV_HUGEPAGE);
+        const unsigned nthr = len >= 8 * H ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
+        std::atomic<size_t> next(0);
+        auto touch = [&]() { for (size_t c; (c = next.fetch_add(1)) < len / H;) for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(touch);
+        touch();
+        for (auto &t : pool) t.join();
+        if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+            std::lock_guard<std::mutex> g(g_pinned_mu);
+            g_pinned_registered.insert(p);
+            *out = p;
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        free(p);
+    }
+    return hipHostMalloc(out, bytes, hipHostMallocDefault);
+}
+static void pinned_free(void *p) {
+    if (!p) return;
+    bool reg;
+    { std::lock_guard<std::mutex> g(g_pinned_mu); reg = g_pinned_registered.erase(p) != 0; }
+    if (reg) { (void)hipHostUnregister(p); free(p); }
+    else (void)hipHostFree(p);
+}
+static void slot_free(int slot, void *p) {
+    if (slot == pgm_ctx::C_HIN) pinned_free(p);
+    else if (slot == pgm_ctx::C_HOST) (void)hipHostFree(p);
+    else (void)hipFree(p);
+}
 
 // ---- arena: one host staging buffer mirrored by one device allocation ------------------------
 struct Arena {   // bump allocator over a slice [off, end) of an external host buffer; offsets are relative to `base`
@@ -133,6 +179,17 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    {   // ... and so is the copy path: the first host-to-device copy of a process takes ~8 ms longer than any later one
+        void *h = nullptr, *d = nullptr;
+        const size_t wb = (size_t)1 << 20;
+        if (hipHostMalloc(&h, wb, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, wb) == hipSuccess) {
+            (void)hipMemcpyAsync(d, h, wb, hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(h, d, wb, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+    }
     *out = c;
     return PGM_OK;
 }
@@ -144,10 +201,10 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);
     for (int k = 0; k < pgm_ctx::SC_DEV; ++k) if (ctx->sc_dev[k]) (void)hipFree(ctx->sc_dev[k]);
-    for (int k = 0; k < pgm_ctx::SC_HOST; ++k) if (ctx->sc_host[k]) (void)hipHostFree(ctx->sc_host[k]);
+    for (int k = 0; k < pgm_ctx::SC_HOST; ++k) if (ctx->sc_host[k]) pinned_free(ctx->sc_host[k]);
     for (int k = 0; k < 2; ++k) if (ctx->sc_ev[k]) (void)hipEventDestroy(ctx->sc_ev[k]);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
-        if (ctx->cache_ptr[k]) { if ((k == pgm_ctx::C_HOST || k == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[k]); else (void)hipFree(ctx->cache_ptr[k]); }
+        if (ctx->cache_ptr[k]) slot_free(k, ctx->cache_ptr[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -333,6 +390,36 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
     }
 }
 
+// Device-only regions of one job (offsets inside the batch's work / cell / result / score buffers) and its slice of the
+// progress counters (pass 1 of pgm_align_batch_create).
+struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog; };
+struct BatchLayout { DevLayout W, C, O, SL; size_t sync_ints = 4; };   // sync: [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
+static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, JobOff &o) {
+    const uint32_t dp = dim <= 20 ? 20 : 64, nb = (n1 - 1 + PGM_ROWS - 1) / PGM_ROWS, tsteps = (n2 - 1) + 63;
+    const uint32_t nblk = (tsteps + PGM_BLOCK - 1) / PGM_BLOCK, maxn = std::max(n1, n2);
+    o.g1f = L.W.take(sizeof(float) * (size_t)dp * n1);
+    o.a1 = L.W.take(sizeof(float) * n1);
+    o.t2 = L.W.take(sizeof(float) * (size_t)dp * n2);
+    o.aux2 = L.W.take(sizeof(float) * (size_t)n2);
+    o.map1 = L.O.take(4 * (size_t)(n1 + n2), 16);
+    o.map2 = L.O.take(4 * (size_t)(n1 + n2), 16);
+    o.tb1 = L.W.take(sizeof(PgmTbNode) * (size_t)n1);
+    o.tb2 = L.W.take(sizeof(PgmTbNode) * (size_t)n2);
+    o.ms = L.W.take(4 * (size_t)maxn);
+    o.mp = L.W.take(4 * (size_t)maxn);
+    o.res = L.O.take(sizeof(PgmJob::Result), 16);
+    o.cells = L.C.take(sizeof(float4) * (size_t)nb * tsteps * 64u, 1024);
+    o.S = L.SL.take(sizeof(float) * (size_t)nb * nblk * 64u * PGM_BLOCK, 1024);
+    o.prog = L.sync_ints;
+    L.sync_ints += (nb + 3) / 4 * 4;
+}
+// upper bound of the flattened input of one graph side with n nodes and E edges (regular + repeat)
+static size_t side_bound_bytes(size_t n, size_t dim, size_t E) {
+    E = std::max<size_t>(E, 1);
+    return n * dim * 8 + n * sizeof(PgmNode2) + 3 * (n + 1) * 4 + E * 28 + 8 * (size_t)PGM_OV_REC * PGM_OV_ENT + 16 * 16;
+}
+static size_t model_bound_bytes(size_t dim) { return (dim * dim + dim) * 8 + 64; }
+
 // take a buffer of at least `bytes` from the context's cache slot, or allocate one (device memory; slot C_HOST: pinned host)
 static hipError_t cache_take(pgm_ctx *ctx, int slot, size_t bytes, void **out, size_t *got) {
     if (ctx->cache_ptr[slot] && ctx->cache_bytes[slot] >= bytes) {
@@ -341,19 +428,20 @@ static hipError_t cache_take(pgm_ctx *ctx, int slot, size_t bytes, void **out, s
         return hipSuccess;
     }
     if (ctx->cache_ptr[slot]) {   // too small: replace
-        if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]);
+        slot_free(slot, ctx->cache_ptr[slot]);
         ctx->cache_ptr[slot] = nullptr; ctx->cache_bytes[slot] = 0;
     }
     *got = bytes;
-    return (slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN) ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    if (slot == pgm_ctx::C_HIN) return pinned_alloc(bytes, out);
+    return slot == pgm_ctx::C_HOST ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
 }
 static void cache_give(pgm_ctx *ctx, int slot, void *p, size_t bytes) {
     if (!p) return;
     if (ctx && (!ctx->cache_ptr[slot] || ctx->cache_bytes[slot] < bytes)) {
-        if (ctx->cache_ptr[slot]) { if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(ctx->cache_ptr[slot]); else (void)hipFree(ctx->cache_ptr[slot]); }
+        if (ctx->cache_ptr[slot]) slot_free(slot, ctx->cache_ptr[slot]);
         ctx->cache_ptr[slot] = p; ctx->cache_bytes[slot] = bytes;
     } else {
-        if ((slot == pgm_ctx::C_HOST || slot == pgm_ctx::C_HIN)) (void)hipHostFree(p); else (void)hipFree(p);
+        slot_free(slot, p);
     }
 }
 
@@ -374,10 +462,10 @@ static hipError_t scratch_dev(pgm_ctx *ctx, int slot, size_t bytes, void **out) 
 static hipError_t scratch_host(pgm_ctx *ctx, int slot, size_t bytes, void **out) {
     bytes = std::max<size_t>(bytes, 16);
     if (ctx->sc_host_bytes[slot] < bytes) {
-        if (ctx->sc_host[slot]) (void)hipHostFree(ctx->sc_host[slot]);
+        if (ctx->sc_host[slot]) pinned_free(ctx->sc_host[slot]);
         ctx->sc_host[slot] = nullptr; ctx->sc_host_bytes[slot] = 0;
         const size_t want = bytes + bytes / 4;
-        hipError_t e = hipHostMalloc(&ctx->sc_host[slot], want, hipHostMallocDefault);
+        hipError_t e = pinned_alloc(want, &ctx->sc_host[slot]);
         if (e != hipSuccess) return e;
         ctx->sc_host_bytes[slot] = want;
     }
@@ -440,13 +528,12 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     if (!ctx || !out || (njobs && (!g1 || !g2 || !model || !scores))) return fail(PGM_ERR_INVALID, "null argument");
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
+    const double tcs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     pgm_align_batch *b = new pgm_align_batch;
     b->njobs = njobs;
     b->jobs.resize(njobs);
-    DevLayout W, C, O, SL;
-    size_t sync_ints = 4;   // [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
-    std::vector<size_t> prog_off(njobs), s_off(njobs);
-    struct Off { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2; };
+    BatchLayout L;
+    typedef JobOff Off;
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
     // pass 1 (serial, O(jobs)): sizes, device layouts, and an upper bound of each job's flattened input
@@ -454,8 +541,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         const size_t n = g->n;
         size_t E = (size_t)std::max(0, g->e_rowptr ? g->e_rowptr[n] : 0);
         if (g->r_rowptr) E += (size_t)std::max(0, g->r_rowptr[n]);
-        E = std::max<size_t>(E, 1);
-        return n * g->dim * 8 + n * sizeof(PgmNode2) + 3 * (n + 1) * 4 + E * 28 + 8 * (size_t)PGM_OV_REC * PGM_OV_ENT + 16 * 16;
+        return side_bound_bytes(n, g->dim, E);
     };
     std::vector<size_t> in_base(njobs + 1, 0);
     for (uint32_t i = 0; i < njobs; ++i) {
@@ -481,35 +567,27 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         b->maxnb = std::max(b->maxnb, J.nb);
         b->cells += (uint64_t)(a->n - 2) * (c->n - 2);
         Off &o = off[i];
-        in_base[i + 1] = in_base[i] + side_bound(a) + side_bound(c) + ((size_t)a->dim * a->dim + a->dim) * 8 + 64;
-        o.g1f = W.take(sizeof(float) * (size_t)J.dp * J.n1);
-        o.a1 = W.take(sizeof(float) * J.n1);
-        o.t2 = W.take(sizeof(float) * (size_t)J.dp * J.n2);
-        o.aux2 = W.take(sizeof(float) * (size_t)J.n2);
-        o.map1 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
-        o.map2 = O.take(4 * (size_t)(J.n1 + J.n2), 16);
-        o.tb1 = W.take(sizeof(PgmTbNode) * (size_t)J.n1);
-        o.tb2 = W.take(sizeof(PgmTbNode) * (size_t)J.n2);
-        o.ms = W.take(4 * (size_t)J.maxn);
-        o.mp = W.take(4 * (size_t)J.maxn);
-        o.res = O.take(sizeof(PgmJob::Result), 16);
-        o.cells = C.take(sizeof(float4) * (size_t)J.nb * J.tsteps * 64u, 1024);
-        s_off[i] = SL.take(sizeof(float) * (size_t)J.nb * J.nblk * 64u * PGM_BLOCK, 1024);
-        prog_off[i] = sync_ints;
-        sync_ints += (J.nb + 3) / 4 * 4;
+        in_base[i + 1] = in_base[i] + side_bound(a) + side_bound(c) + model_bound_bytes(a->dim);
+        layout_job(L, J.n1, J.n2, J.dim, o);
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
     // The device buffers and the pinned result block are allocated (or taken from the context's cache) on a thread of their own
     // while the jobs are being flattened: all sizes are known after pass 1.
     b->in_bytes = std::max<size_t>(in_base[njobs], 16);
-    b->work_bytes = std::max<size_t>(W.bytes, 16);
-    b->cell_bytes = std::max<size_t>(C.bytes, 16);
-    b->out_bytes = std::max<size_t>(O.bytes, 16);
-    b->s_bytes = std::max<size_t>(SL.bytes, 16);
+    b->work_bytes = std::max<size_t>(L.W.bytes, 16);
+    b->cell_bytes = std::max<size_t>(L.C.bytes, 16);
+    b->out_bytes = std::max<size_t>(L.O.bytes, 16);
+    b->s_bytes = std::max<size_t>(L.SL.bytes, 16);
+    const size_t sync_ints = L.sync_ints;
     b->sync_ints = sync_ints;
     hipError_t alloc_err = hipSuccess, alloc_host_err = hipSuccess;
     uint8_t *h_out_dev = nullptr;
+    const bool cprof = getenv("PGM_HOST_PROFILE") != nullptr;   // tools: where the time of create goes
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tc0 = now_ms();
+    double tc_alloc = 0, tc_hostalloc = 0;
     std::thread alloc_thread([&]() {
+        const double ta0 = now_ms();
         hipError_t e2 = hipSetDevice(ctx->device);
         if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN]);
         if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK]);
@@ -520,6 +598,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs));
         if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs));
         alloc_err = e2;
+        tc_alloc = now_ms() - ta0;
         // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
         // into it over PCIe while the kernel is still running
         if (e2 == hipSuccess) {
@@ -528,6 +607,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             if (e3 == hipSuccess) e3 = hipHostGetDevicePointer((void **)&h_out_dev, b->h_out, 0);
             alloc_host_err = e3;
         }
+        tc_hostalloc = now_ms() - ta0 - tc_alloc;
     });
     // pass 2 (host threads): flatten every job straight into a pinned staging buffer (kept by the context)
     hipError_t e;
@@ -536,6 +616,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
+    const double tc1 = now_ms();
     {
         std::atomic<int> bad(-1);
         std::atomic<uint32_t> next_job(0);
@@ -627,7 +708,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             return fail(PGM_ERR_INVALID, "invalid graph in job " + std::to_string(i));
         }
     }
+    const double tc2 = now_ms();
     alloc_thread.join();
+    const double tc3 = now_ms();
     if (alloc_err != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(alloc_err == hipErrorOutOfMemory ? PGM_ERR_NOMEM : PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(alloc_err));
@@ -661,8 +744,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.hmap1 = (uint32_t *)(h_out_dev + o.map1); J.hmap2 = (uint32_t *)(h_out_dev + o.map2);
         J.hresult = (PgmJob::Result *)(h_out_dev + o.res);
         J.cells = (float4 *)(b->d_cells + o.cells);
-        J.S = (float *)(b->d_S + s_off[i]);
-        J.prog = b->d_sync + prog_off[i];
+        J.S = (float *)(b->d_S + o.S);
+        J.prog = b->d_sync + o.prog;
     }
     b->order.resize(njobs);
     std::iota(b->order.begin(), b->order.end(), 0u);
@@ -736,6 +819,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             if (++next[j] < per_job[j].size()) pending.push({per_job[j][next[j]].rem > eager * rmax ? now : now + it.gap, j});
         }
     }
+    const double tc4 = now_ms();
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 176 * items.size());   // 6 words per item + 16 per item for the helper wavefronts
@@ -752,6 +836,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
     }
     for (int k = 0; k < 5; ++k) (void)hipEventCreate(&b->ev[k]);
+    if (cprof)
+        fprintf(stderr, "    create: sizes %.2f ms, pinned input block %.2f, flatten %.2f, wait for the allocations %.2f (device %.2f, pinned results %.2f), work list %.2f, upload of %.1f MB %.2f\n",
+                tc0 - tcs, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc_alloc, tc_hostalloc, tc4 - tc3, b->in_bytes / 1e6, now_ms() - tc4);
     *out = b;
     return PGM_OK;
 }

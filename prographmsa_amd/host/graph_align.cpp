@@ -127,7 +127,7 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
     std::vector<pgm_align_out> out(n);
     std::vector<AlignmentResult> res(n);
     Backend &be = default_backend();
-    for (uint32_t i = 0; i < n; ++i) {
+    parallel_for(n, [&](size_t i) {   // (DynProgScores walks both graphs: averageAlignmentLength)
         f1[i] = g1[i]->flat();
         f2[i] = g2[i]->flat();
         fm[i].M = model[i]->M.data();
@@ -140,6 +140,8 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
         out[i].map2 = res[i].mapping2.data();
         out[i].len = 0;
         out[i].status = 0;
+    });
+    for (uint32_t i = 0; i < n; ++i) {
         be.cells_aligned += (uint64_t)(g1[i]->size() - 2) * (g2[i]->size() - 2);
         if (!g_dump_path.empty()) dump_job(f1[i], f2[i], fm[i], sc[i]);
     }

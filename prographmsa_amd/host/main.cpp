@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <malloc.h>
 
 using namespace pgm;
 
@@ -67,6 +68,7 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         old_result = result;
     }
     if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
+    if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "[%.1f ms] back in main\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     double t_prog = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     out_tree = tree;
 
@@ -89,6 +91,14 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
 }
 
 int main(int argc, char **argv) {
+    // The graphs of a level are hundreds of vectors of 0.1-1 MB built and dropped by the host threads: with glibc's defaults
+    // each is an mmap / munmap of its own (page faults on every reuse, the address-space lock shared by all threads), and
+    // the heap is trimmed back to the system whenever its top is freed.  Keep them in the heaps instead.
+    if (!getenv("PGM_MALLOC_DEFAULTS")) {
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+        mallopt(M_TOP_PAD, 64 << 20);
+    }
     try {
         bool iters_set = false, stats = false, indel_set = false, edgehl_set = false, maxdist_set = false, cutdist_set = false;
         std::string dump, dist_dump;

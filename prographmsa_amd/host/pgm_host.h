@@ -20,6 +20,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <functional>
 
 #include "../../include/pgm_hip.h"
 
@@ -327,6 +328,9 @@ struct ProgressiveAlignmentResult {   // ProgressiveAlignment.h:27-37
     bool is_csprofile = false;
 };
 // align_progressive_results (ProgressiveAlignment.h:413-476) for a whole guide-tree level at once.
+// fn(0..n-1) on the host threads (PGM_HOST_THREADS, at most 16); exceptions are rethrown on the caller
+void parallel_for(size_t n, const std::function<void(size_t)> &fn);
+
 // progressive_alignment (ProgressiveAlignment.cpp:12-71): same post-order results as the reference's
 // recursion; internal nodes whose children are finished are aligned together in one batch.
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,

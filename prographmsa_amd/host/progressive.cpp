@@ -31,7 +31,7 @@ static void extend_alignment(const Alphabet &a, ProgressiveAlignmentResult &resu
     }
 }
 
-static void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
     unsigned nt = std::thread::hardware_concurrency();
     if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
     nt = std::max(1u, std::min(nt, 16u));
@@ -80,6 +80,7 @@ static int collect(const PhyTree &t, std::vector<Node> &nodes) {
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
                                                  const PhyTree &tree, const CSProfile *csprofile,
                                                  const ModelFactory &model_factory) {
+    const auto tl0 = std::chrono::steady_clock::now();
     std::vector<Node> nodes;
     int root = collect(tree, nodes);
     int maxh = nodes[root].height;
@@ -135,6 +136,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         }
     }
 
+    if (getenv("PGM_HOST_PROFILE"))
+        fprintf(stderr, "leaves: %zu, %.1f ms\n", leaves.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     // ---- internal nodes, one guide-tree level per batch (ProgressiveAlignment.h:413-476) ----
     for (int h = 1; h <= maxh; ++h) {
         std::vector<int> level;
@@ -214,11 +217,18 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         });
         const auto tp3 = std::chrono::steady_clock::now();
         if (getenv("PGM_HOST_PROFILE"))
-            fprintf(stderr, "level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n", h, L,
+            fprintf(stderr, "[%.1f ms] level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(tp3 - tl0).count(), h, L,
                     std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
                     std::chrono::duration<double, std::milli>(tp3 - tp2).count());
     }
-    return std::move(nodes[root].res);
+    ProgressiveAlignmentResult out = std::move(nodes[root].res);
+    if (getenv("PGM_HOST_PROFILE"))
+        fprintf(stderr, "[%.1f ms] root result taken\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
+    nodes.clear();
+    if (getenv("PGM_HOST_PROFILE"))
+        fprintf(stderr, "[%.1f ms] nodes released\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
+    return out;
 }
 
 }  // namespace pgm
