@@ -25,6 +25,7 @@
 #include "pgm_csprofile_kernels.h"
 #include "pgm_dist_kernels.h"
 #include "pgm_merge_kernels.h"
+#include "pgm_pool.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
@@ -63,6 +64,11 @@ struct pgm_ctx {
 // thread that touches the address space meanwhile (hipHostFree: another 8 ms).  A 2 MB aligned block with MADV_HUGEPAGE,
 // first touched by a few threads and registered afterwards, is pinned in ~1 ms (tools/micro/pin_bench.hip: fill 0.9 ms,
 // hipHostRegister 0.2 ms, same copy rate).  Blocks that could not be registered fall back to hipHostMalloc.
+// the library's host threads (flattening, staging copies, first touch of pinned blocks)
+static pgm_pool::Pool &lib_pool() {
+    static pgm_pool::Pool pool(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    return pool;
+}
 static std::mutex g_pinned_mu;
 static std::unordered_set<void *> g_pinned_registered;
 static hipError_t pinned_alloc(size_t bytes, void **out) {
@@ -70,13 +76,7 @@ static hipError_t pinned_alloc(size_t bytes, void **out) {
     void *p = aligned_alloc(H, len);
     if (p) {
         (void)madvise(p, len, MADV_HUGEPAGE);
-        const unsigned nthr = len >= 8 * H ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
-        std::atomic<size_t> next(0);
-        auto touch = [&]() { for (size_t c; (c = next.fetch_add(1)) < len / H;) for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(touch);
-        touch();
-        for (auto &t : pool) t.join();
+        (void)lib_pool().run(len / H, len >= 8 * H ? 8u : 1u, [&](size_t c) { for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; });
         if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
             std::lock_guard<std::mutex> g(g_pinned_mu);
             g_pinned_registered.insert(p);
@@ -586,6 +586,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tc0 = now_ms();
     double tc_alloc = 0, tc_hostalloc = 0;
+    std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
+    std::atomic<int> upload_err((int)hipSuccess);
     std::thread alloc_thread([&]() {
         const double ta0 = now_ms();
         hipError_t e2 = hipSetDevice(ctx->device);
@@ -598,6 +600,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs));
         if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs));
         alloc_err = e2;
+        alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
         tc_alloc = now_ms() - ta0;
         // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
         // into it over PCIe while the kernel is still running
@@ -619,19 +622,17 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     const double tc1 = now_ms();
     {
         std::atomic<int> bad(-1);
-        std::atomic<uint32_t> next_job(0);
         const bool job_stats = getenv("PGM_JOB_STATS") != nullptr;                                  // tools only
         const bool no_helper = getenv("PGM_NO_HELPER") != nullptr;                                  // experiments only
         const int mode2_min_bands = getenv("PGM_MODE2_BANDS") ? atoi(getenv("PGM_MODE2_BANDS")) : 20;   // experiments only
-        auto work = [&]() {
-            for (;;) {
-                const uint32_t i = next_job.fetch_add(1);
-                if (i >= njobs) break;
+        auto work = [&](size_t job_index) {
+            {
+                const uint32_t i = (uint32_t)job_index;
                 Arena A;
                 A.base = b->h_in; A.off = in_base[i]; A.end = in_base[i + 1];
                 PgmJob &J = b->jobs[i];
                 Off &o = off[i];
-                if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); continue; }
+                if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); return; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
                 // LDS of one sweeping wavefront: W / Y history of hD steps x (64 lanes + 16 virtual lanes), X history of hDX
                 // steps x 64 lanes, 128 column summaries.  A pair (y - dy, x - dx) is read dy + dx steps back and the virtual
@@ -693,14 +694,18 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 }
                 o.M = A.put(model[i]->M, sizeof(double) * J.dim * J.dim);
                 o.pi = A.put(model[i]->pi, sizeof(double) * J.dim);
-                if (A.overflow) bad.store((int)i);
+                if (A.overflow) { bad.store((int)i); return; }
+                // the job's slice of the input image goes to the device while the other jobs are still being flattened
+                int st;
+                while ((st = alloc_state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+                if (st == 1) {
+                    (void)hipSetDevice(ctx->device);
+                    const hipError_t eu = hipMemcpyAsync(b->d_in + in_base[i], b->h_in + in_base[i], A.off - in_base[i], hipMemcpyHostToDevice, ctx->stream);
+                    if (eu != hipSuccess) upload_err.store((int)eu);
+                }
             }
         };
-        const unsigned nthr = std::max(1u, std::min(8u, std::min(njobs, std::thread::hardware_concurrency())));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        (void)lib_pool().run(njobs, 16, work);
         if (bad.load() >= 0) {
             const int i = bad.load();
             alloc_thread.join();
@@ -827,7 +832,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
-    if ((e = hipMemcpyAsync(b->d_in, b->h_in, b->in_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+    if ((e = (hipError_t)upload_err.load()) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
@@ -948,7 +953,7 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
 
 void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (!b) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }   // nothing of the batch is in flight when its buffers go back to the cache
     for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
     cache_give(ctx, pgm_ctx::C_IN, b->d_in, b->cap[pgm_ctx::C_IN]);

@@ -6,6 +6,7 @@
 // alignGraphs call; the per-node host work (CleanedGraph, mergeGraphs, extend_alignment) runs on a
 // few host threads.  The values produced per node are those of the reference's recursion.
 #include "pgm_host.h"
+#include "../csrc/pgm_pool.h"
 
 #include <algorithm>
 #include <chrono>
@@ -17,35 +18,37 @@
 namespace pgm {
 
 // extend_alignment (ProgressiveAlignment.h:245-264)
+void parallel_for(size_t n, const std::function<void(size_t)> &fn);
+// `spread`: the rows are filled on the host threads (the few nodes near the root carry hundreds of rows each)
 static void extend_alignment(const Alphabet &a, ProgressiveAlignmentResult &result, const std::vector<index_t> &mapping,
-                             const std::map<std::string, sequence_t> &aligned_sequences) {
-    for (const auto &kv : aligned_sequences) {
-        sequence_t extended(result.graph.size() - 2, a.unknown());
-        const sequence_t &original = kv.second;
+                             const std::map<std::string, sequence_t> &aligned_sequences, bool spread) {
+    std::vector<std::pair<const sequence_t *, sequence_t *>> rows;
+    rows.reserve(aligned_sequences.size());
+    for (const auto &kv : aligned_sequences) rows.emplace_back(&kv.second, &result.aligned_sequences[kv.first]);
+    const index_t n = result.graph.size();
+    auto fill = [&](size_t r) {
+        sequence_t extended(n - 2, a.unknown());
+        const sequence_t &original = *rows[r].first;
         index_t k = 0;
-        for (index_t j = 1; j < result.graph.size() - 1; ++j) {
+        for (index_t j = 1; j < n - 1; ++j) {
             if (mapping[j] != (index_t)-1) extended[j - 1] = original[k++];
             else extended[j - 1] = a.gap();
         }
-        result.aligned_sequences[kv.first] = extended;
-    }
+        *rows[r].second = std::move(extended);
+    };
+    if (spread && rows.size() >= 64) parallel_for(rows.size(), fill);
+    else for (size_t r = 0; r < rows.size(); ++r) fill(r);
 }
 
 void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char *e = getenv("PGM_HOST_THREADS")) nt = (unsigned)atoi(e);
-    nt = std::max(1u, std::min(nt, 16u));
-    nt = (unsigned)std::min<size_t>(nt, n);
-    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::vector<std::thread> th;
-    std::vector<std::string> errs(nt);
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&, t]() {
-            try { for (size_t i = t; i < n; i += nt) fn(i); }
-            catch (std::exception &e) { errs[t] = e.what(); }
-        });
-    for (auto &t : th) t.join();
-    for (auto &e : errs) if (!e.empty()) throw pgm_exception(e);
+    static unsigned nt = []() {
+        unsigned v = std::thread::hardware_concurrency();
+        if (const char *e = getenv("PGM_HOST_THREADS")) v = (unsigned)atoi(e);
+        return std::max(1u, std::min(v, 16u));
+    }();
+    static pgm_pool::Pool pool(nt);   // persistent: a level has half a dozen sections of a millisecond or two
+    const std::string err = pool.run(n, nt, fn);
+    if (!err.empty()) throw pgm_exception(err);
 }
 
 namespace {
@@ -178,6 +181,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             plans[k] = planMerge(nodes[nd.child[0]].res.graph, nodes[nd.child[1]].res.graph, ar[k].mapping1, ar[k].mapping2);
             profiles[k].assign((size_t)a.DIM * plans[k].mapping1.size(), 0.0);
         });
+        const auto tq0 = std::chrono::steady_clock::now();
         bool on_device = false;
         if (!getenv("PGM_HOST_MERGE")) {
             std::vector<pgm_merge_job> mj(L);
@@ -195,6 +199,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             on_device = default_backend().merge_profiles_batch((uint32_t)L, mj.data());
             default_backend().seconds_merge_profiles += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
         }
+        const auto tq1 = std::chrono::steady_clock::now();
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
@@ -206,8 +211,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             if (!on_device) mergeProfilesHost(r1.graph, r2.graph, p.model1, p.model2, plans[k], profiles[k]);
             AncestralResult anc = finishMerge(r1.graph, r2.graph, plans[k], profiles[k], (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
             result.graph = anc.graph;
-            extend_alignment(a, result, anc.mapping1, r1.aligned_sequences);
-            extend_alignment(a, result, anc.mapping2, r2.aligned_sequences);
+            extend_alignment(a, result, anc.mapping1, r1.aligned_sequences, L == 1);
+            extend_alignment(a, result, anc.mapping2, r2.aligned_sequences, L == 1);
             // children are no longer needed (the reference copies them by value and drops them)
             r1 = ProgressiveAlignmentResult();
             r2 = ProgressiveAlignmentResult();
@@ -220,7 +225,9 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             fprintf(stderr, "[%.1f ms] level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n",
                     std::chrono::duration<double, std::milli>(tp3 - tl0).count(), h, L,
                     std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
-                    std::chrono::duration<double, std::milli>(tp3 - tp2).count());
+                    std::chrono::duration<double, std::milli>(tp3 - tp2).count()),
+            fprintf(stderr, "    post: plans %.1f ms, node profiles %.1f, edges / graphs / extend %.1f\n", std::chrono::duration<double, std::milli>(tq0 - tp2).count(),
+                    std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tp3 - tq1).count());
     }
     ProgressiveAlignmentResult out = std::move(nodes[root].res);
     if (getenv("PGM_HOST_PROFILE"))
