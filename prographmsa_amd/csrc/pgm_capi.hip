@@ -41,9 +41,9 @@ struct pgm_ctx {
     hipStream_t stream = nullptr;
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
     // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
-    enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SLOTS };   // C_HOST, C_HIN: pinned host memory
-    void *cache_ptr[C_SLOTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cache_bytes[C_SLOTS] = {0, 0, 0, 0, 0, 0, 0};
+    enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SMALL, C_SLOTS };   // C_HOST, C_HIN: pinned host memory; C_SMALL: the batch's counters, job descriptors, work list
+    void *cache_ptr[C_SLOTS] = {};
+    size_t cache_bytes[C_SLOTS] = {};
     hipDeviceProp_t prop;
     float nw_ms = 0, cs_ms = 0, ml_ms = 0, merge_ms = 0;
     // grow-only scratch buffers of the all-pairs / context-profile calls (slot = position in the call's buffer list): a
@@ -136,7 +136,8 @@ struct pgm_align_batch {
     size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // real sizes of the buffers taken from the context's cache
     uint8_t *h_out = nullptr;          // pinned result block, same layout: written by the kernel itself, read by fetch
     uint8_t *h_in = nullptr;           // pinned staging buffer of the flattened inputs (one H2D copy per create)
-    int *h_flag = nullptr;
+    int *h_flag = nullptr;            // (inside h_out, after the results)
+    uint8_t *d_small = nullptr;       // d_sync, d_jobs, d_order, d_items live in this one cached allocation (no hipMalloc / hipFree per batch)
     uint8_t *d_S = nullptr;           // emission scores in fill order
     int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
     size_t sync_ints = 0, s_bytes = 0;
@@ -586,6 +587,13 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tc0 = now_ms();
     double tc_alloc = 0, tc_hostalloc = 0;
+    // one small allocation: progress counters, job descriptors, size order, work list (at most one item per band)
+    size_t total_bands = 0;
+    for (uint32_t i = 0; i < njobs; ++i) total_bands += b->jobs[i].nb;
+    DevLayout SM;
+    const size_t small_sync = SM.take(sync_ints * sizeof(int)), small_jobs = SM.take(sizeof(PgmJob) * std::max(1u, njobs)),
+                 small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands));
+    const size_t small_bytes = SM.bytes;
     std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
     std::atomic<int> upload_err((int)hipSuccess);
     std::thread alloc_thread([&]() {
@@ -596,17 +604,21 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS]);
         if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT]);
         if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S]);
-        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_sync, sync_ints * sizeof(int));
-        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_jobs, sizeof(PgmJob) * std::max(1u, njobs));
-        if (e2 == hipSuccess) e2 = hipMalloc((void **)&b->d_order, 4 * std::max(1u, njobs));
+        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_SMALL, small_bytes, (void **)&b->d_small, &b->cap[pgm_ctx::C_SMALL]);
+        if (e2 == hipSuccess) {
+            b->d_sync = (int *)(b->d_small + small_sync);
+            b->d_jobs = (PgmJob *)(b->d_small + small_jobs);
+            b->d_order = (uint32_t *)(b->d_small + small_order);
+            b->d_items = (PgmItem *)(b->d_small + small_items);
+        }
         alloc_err = e2;
         alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
         tc_alloc = now_ms() - ta0;
         // pinned result block, same layout as d_out: the traceback workers write the finished mappings and result records
         // into it over PCIe while the kernel is still running
         if (e2 == hipSuccess) {
-            hipError_t e3 = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST]);
-            if (e3 == hipSuccess) e3 = hipHostMalloc((void **)&b->h_flag, 4 * sizeof(int), hipHostMallocDefault);
+            hipError_t e3 = cache_take(ctx, pgm_ctx::C_HOST, b->out_bytes + 64, (void **)&b->h_out, &b->cap[pgm_ctx::C_HOST]);
+            if (e3 == hipSuccess) b->h_flag = (int *)(b->h_out + (b->out_bytes + 15) / 16 * 16);
             if (e3 == hipSuccess) e3 = hipHostGetDevicePointer((void **)&h_out_dev, b->h_out, 0);
             alloc_host_err = e3;
         }
@@ -835,9 +847,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 176 * items.size());   // 6 words per item + 16 per item for the helper wavefronts
-    if ((e = hipMalloc((void **)&b->d_items, sizeof(PgmItem) * std::max<size_t>(1, items.size()))) != hipSuccess) {
+    if (items.size() > std::max<size_t>(1, total_bands)) {   // (cannot happen: an item holds at least one band)
         pgm_align_batch_destroy(ctx, b);
-        return fail(PGM_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return fail(PGM_ERR_DEVICE, "work list longer than the number of bands");
     }
     if ((e = (hipError_t)upload_err.load()) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
@@ -968,14 +980,10 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     cache_give(ctx, pgm_ctx::C_CELLS, b->d_cells, b->cap[pgm_ctx::C_CELLS]);
     cache_give(ctx, pgm_ctx::C_OUT, b->d_out, b->cap[pgm_ctx::C_OUT]);
     cache_give(ctx, pgm_ctx::C_S, b->d_S, b->cap[pgm_ctx::C_S]);
-    if (b->d_sync) (void)hipFree(b->d_sync);
+    cache_give(ctx, pgm_ctx::C_SMALL, b->d_small, b->cap[pgm_ctx::C_SMALL]);
     cache_give(ctx, pgm_ctx::C_HOST, b->h_out, b->cap[pgm_ctx::C_HOST]);
     cache_give(ctx, pgm_ctx::C_HIN, b->h_in, b->cap[pgm_ctx::C_HIN]);
-    if (b->h_flag) (void)hipHostFree(b->h_flag);
-    if (b->d_items) (void)hipFree(b->d_items);
     if (b->d_trace) (void)hipFree(b->d_trace);
-    if (b->d_jobs) (void)hipFree(b->d_jobs);
-    if (b->d_order) (void)hipFree(b->d_order);
     delete b;
 }
 
