@@ -64,7 +64,9 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
             if (!it->first.empty() && it->first[0] == '(') it = result.aligned_sequences.erase(it); else ++it;
         if (i > 0 && result.aligned_sequences == old_result.aligned_sequences) break;   // converged
         delete tree;
+        const auto tt0 = std::chrono::steady_clock::now();
         tree = TreeNJ(a, result.aligned_sequences, model_factory.get(), true);
+        if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "guide tree from the alignment: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count());
         old_result = result;
     }
     if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
