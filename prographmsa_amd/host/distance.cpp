@@ -373,8 +373,9 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     std::vector<uint32_t> gaps(np, 0);
     Backend &be = default_backend();
     bool done = false;
-    if (getenv("PGM_DEVICE_MLDIST") && np) {
-        // the N^2 L column scan on the device: value() per residue, -1 for a gap, -2 for a residue without a value
+    if (!getenv("PGM_HOST_COUNTS") && np) {
+        // the N^2 L column scan on the device (integer counts, bit-exact: on by default, unlike the ML estimates that follow):
+        // value() per residue, -1 for a gap, -2 for a residue without a value
         auto t0 = std::chrono::steady_clock::now();
         std::vector<int8_t> mat((size_t)n * L);
         for (uint32_t i = 0; i < n; ++i)
@@ -422,7 +423,11 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
         be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     }
     std::vector<double> seqlen(np, ((double)L + (double)L) / 2.0);
+    const auto tq0 = std::chrono::steady_clock::now();
     computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    if (getenv("PGM_HOST_PROFILE"))
+        fprintf(stderr, "  prealigned distances: pair counts %s, estimates %.1f ms\n", done ? "on the device" : "on the host",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
     dump_distances(distances);
     return distances;
 }
@@ -433,9 +438,15 @@ PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs
         std::vector<std::string> order;
         for (const auto &kv : seqs) order.push_back(kv.first);
         DistanceFactoryPrealigned df(a, mf);
+        const auto tq0 = std::chrono::steady_clock::now();
         DistanceMatrix dist = df.computePwDistances(seqs, order);
         for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
-        return midpointRoot(buildNJTree(order, dist));
+        const auto tq1 = std::chrono::steady_clock::now();
+        PhyTree *t = midpointRoot(buildNJTree(order, dist));
+        if (getenv("PGM_HOST_PROFILE"))
+            fprintf(stderr, "  TreeNJ: distances %.1f ms, BioNJ + rooting %.1f ms\n", std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
+        return t;
     }
     if (!cmdlineopts.nwdist_flag)
         error("initial guide tree: only -a/--nwdist (DistanceFactoryAlign) is built here; pass --tree or -a");

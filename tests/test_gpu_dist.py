@@ -68,8 +68,11 @@ def _dump(args, fasta, tmp_path, device):
     path = str(tmp_path / ("dist_%d.bin" % device))
     env = dict(os.environ)
     env.pop("PGM_DEVICE_MLDIST", None)
+    env.pop("PGM_HOST_COUNTS", None)
     if device:
         env["PGM_DEVICE_MLDIST"] = "1"
+    else:
+        env["PGM_HOST_COUNTS"] = "1"     # (the pair counts of an alignment are on the device by default: bit-exact integers)
     r = subprocess.run([pg.PGMSA_PATH] + args + ["--dump_dist", path, fasta], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     buf = open(path, "rb").read()
