@@ -76,7 +76,7 @@ static hipError_t pinned_alloc(size_t bytes, void **out) {
     void *p = aligned_alloc(H, len);
     if (p) {
         (void)madvise(p, len, MADV_HUGEPAGE);
-        (void)lib_pool().run(len / H, len >= 8 * H ? 8u : 1u, [&](size_t c) { for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; });
+        (void)lib_pool().run(len / H, len >= 8 * H ? 16u : 1u, [&](size_t c) { for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; });
         if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
             std::lock_guard<std::mutex> g(g_pinned_mu);
             g_pinned_registered.insert(p);
