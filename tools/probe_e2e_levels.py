@@ -7,6 +7,7 @@ import prographmsa_amd as pg
 tmp = tempfile.mkdtemp()
 CFG = os.environ.get("PROBE_CFG", "c3")
 fam, tree, extra = {"c3": (gen.gen(256, 1000, 3), "c3.tree", ["-m"]), "c5": (gen.gen(1024, 600, 6), "c5.tree", []),
+                    "c4": (gen.gen_codon(128, 1000, 4), "c4.tree", ["--codon"]),
                     "default": (gen.gen(256, 1000, 3), None, ["-a"])}[CFG]
 fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam))
 VARIANTS = [dict(x.split("=") for x in v.split(",") if x) for v in os.environ.get("PROBE_VARIANTS", "").split(";")]
