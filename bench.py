@@ -152,15 +152,19 @@ def main():
         with open(fa, "w") as f:
             f.write(fasta_text)
         dump = os.path.join(tmp, name + ".jobs")
-        t0 = time.time()
         r = subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "--stats", fa], capture_output=True, text=True, env=env)
         if r.returncode != 0:
             raise SystemExit("pgmsa failed: " + r.stderr)
-        wall = time.time() - t0
-        st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
-        st["wall_s"] = round(wall, 3)
         js = J.load_jobs(dump)
         os.remove(dump)
+        # the driver's own times come from a second run without the job dump (writing the jobs to disk is not part of the product)
+        t0 = time.time()
+        r2 = subprocess.run([pg.PGMSA_PATH] + flags + ["--stats", fa], capture_output=True, text=True, env=env)
+        wall = time.time() - t0
+        if r2.returncode != 0 or r2.stdout != r.stdout:
+            raise SystemExit("pgmsa: second run failed or differs: " + r2.stderr)
+        st = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+        st["wall_s"] = round(wall, 3)
         return js, st, hashlib.md5(r.stdout.encode()).hexdigest()
 
     headline = (args.nseq == 256 and args.len == 1000)
@@ -414,7 +418,7 @@ def main():
             "configs": configs,
             "end_to_end": {"pgmsa_wall_s": stats["wall_s"], "init_s": stats.get("init_s"), "progressive_s": stats["progressive_s"], "align_call_s": stats["align_s"],
                            "fasta_identical_to_reference": (out_md5 == md5s.get("c3.out.fa")) if headline else None,
-                           "note": "untimed set-up run of the product driver; progressive_s incl. host merges, H2D/D2H and hipMalloc, init_s = HIP start-up + code object load (before the stage clocks start)",
+                           "note": "a run of the product driver outside the timed region (without the job dump); progressive_s incl. host merges, H2D/D2H and allocations, init_s = HIP start-up + code object load (before the stage clocks start)",
                            "default_flow": default_flow},
         }
         if world == 1 and not args.no_cpu_baseline:
