@@ -59,16 +59,17 @@ struct pgm_ctx {
     double *cs_lprofiles = nullptr, *cs_centre = nullptr, *cs_priors = nullptr;
 };
 
+// the library's host threads (flattening and chunked upload of the jobs, staging copies, first touch of pinned blocks)
+static pgm_pool::Pool &lib_pool() {
+    static pgm_pool::Pool pool(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    return pool;
+}
+
 // ---- pinned host blocks ---------------------------------------------------------------------------
 // hipHostMalloc of the staging block of a 128-job level (76 MB) takes 10-14 ms in a cold process and stalls every other
 // thread that touches the address space meanwhile (hipHostFree: another 8 ms).  A 2 MB aligned block with MADV_HUGEPAGE,
 // first touched by a few threads and registered afterwards, is pinned in ~1 ms (tools/micro/pin_bench.hip: fill 0.9 ms,
 // hipHostRegister 0.2 ms, same copy rate).  Blocks that could not be registered fall back to hipHostMalloc.
-// the library's host threads (flattening, staging copies, first touch of pinned blocks)
-static pgm_pool::Pool &lib_pool() {
-    static pgm_pool::Pool pool(std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-    return pool;
-}
 static std::mutex g_pinned_mu;
 static std::unordered_set<void *> g_pinned_registered;
 static hipError_t pinned_alloc(size_t bytes, void **out) {
@@ -624,7 +625,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         }
         tc_hostalloc = now_ms() - ta0 - tc_alloc;
     });
-    // pass 2 (host threads): flatten every job straight into a pinned staging buffer (kept by the context)
+    // pass 2 (the library's host threads): flatten every job straight into a pinned staging buffer (kept by the context)
     hipError_t e;
     if ((e = cache_take(ctx, pgm_ctx::C_HIN, b->in_bytes, (void **)&b->h_in, &b->cap[pgm_ctx::C_HIN])) != hipSuccess) {
         alloc_thread.join();
