@@ -39,8 +39,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (a step is ~4.7 ms; this pool's hosts stall a GPU wait for ~20 ms about once a second, whatever runs — tools/probe_step.py —
+    # so a 20-step region either misses the stall or carries 1 ms of it per step; 200 steps carry their share)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nseq", type=int, default=256, help="debug: smaller family (changes the workload; not the headline)")
     ap.add_argument("--len", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,14 +159,20 @@ def main():
             raise SystemExit("pgmsa failed: " + r.stderr)
         js = J.load_jobs(dump)
         os.remove(dump)
-        # the driver's own times come from a second run without the job dump (writing the jobs to disk is not part of the product)
-        t0 = time.time()
-        r2 = subprocess.run([pg.PGMSA_PATH] + flags + ["--stats", fa], capture_output=True, text=True, env=env)
-        wall = time.time() - t0
-        if r2.returncode != 0 or r2.stdout != r.stdout:
-            raise SystemExit("pgmsa: second run failed or differs: " + r2.stderr)
-        st = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
-        st["wall_s"] = round(wall, 3)
+        # the driver's own times come from further runs without the job dump (writing the jobs to disk is not part of the
+        # product): the median of three by progressive_s (a run is 50-150 ms; one ~20 ms stall of the host changes it visibly)
+        runs = []
+        for _ in range(3):
+            t0 = time.time()
+            r2 = subprocess.run([pg.PGMSA_PATH] + flags + ["--stats", fa], capture_output=True, text=True, env=env)
+            wall = time.time() - t0
+            if r2.returncode != 0 or r2.stdout != r.stdout:
+                raise SystemExit("pgmsa: repeated run failed or differs: " + r2.stderr)
+            st = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+            st["wall_s"] = round(wall, 3)
+            runs.append(st)
+        st = sorted(runs, key=lambda q: q["progressive_s"])[1]
+        st["progressive_s_of_3_runs"] = sorted(q["progressive_s"] for q in runs)
         return js, st, hashlib.md5(r.stdout.encode()).hexdigest()
 
     headline = (args.nseq == 256 and args.len == 1000)
@@ -385,10 +393,10 @@ def main():
             b2 = J.Batch(ctx, js)
             b2.run(); b2.fetch_raw()
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(40):
                 b2.run()
                 b2.fetch_raw()
-            d2 = (time.perf_counter() - t0) / 5
+            d2 = (time.perf_counter() - t0) / 40
             tm = sorted(b2.time(1) for _ in range(3))[1]
             configs[name] = {"jobs": len(js), "cells": b2.cells, "dim": js[0].g1.dim, "ms_per_pass": round(d2 * 1e3, 3),
                              "gcups": round(b2.cells / d2 / 1e9, 3), "ms": {"prep": round(tm[0], 3), "emission": round(tm[1], 3), "fill_and_traceback": round(tm[2], 3)},
@@ -418,7 +426,8 @@ def main():
             "configs": configs,
             "end_to_end": {"pgmsa_wall_s": stats["wall_s"], "init_s": stats.get("init_s"), "progressive_s": stats["progressive_s"], "align_call_s": stats["align_s"],
                            "fasta_identical_to_reference": (out_md5 == md5s.get("c3.out.fa")) if headline else None,
-                           "note": "a run of the product driver outside the timed region (without the job dump); progressive_s incl. host merges, H2D/D2H and allocations, init_s = HIP start-up + code object load (before the stage clocks start)",
+                           "progressive_s_of_3_runs": stats.get("progressive_s_of_3_runs"),
+                           "note": "the median of three runs of the product driver outside the timed region (without the job dump); progressive_s incl. host merges, H2D/D2H and allocations, init_s = HIP start-up + code object load (before the stage clocks start)",
                            "default_flow": default_flow},
         }
         if world == 1 and not args.no_cpu_baseline:

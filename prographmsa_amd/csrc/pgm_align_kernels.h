@@ -182,6 +182,75 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     if (tb0 >= J.nblk || 4u * RB * blockIdx.y >= J.nb) return;
     const uint32_t t0 = tb0 * PGM_BLOCK;
     const int cbase = (int)t0 - 63;
+    if (DP == 20 && RB == 1) {
+        // Rows of a sequence graph (a leaf of the guide tree: half of the cells of a progressive pass) hold a single 1.0, START
+        // and the rows beyond the graph hold nothing.  The sum of such a row with column c is ((+0 + 0 T[c][0]) + ...) + 1 T[c][s]
+        // + ... = 0.0f + T[c][s] (the other terms are zeros of either sign), and a1 depends on s alone: the score of a cell is
+        // a function of (s, c).  If every row of the workgroup is of that kind, the 21 x COLS scores are evaluated once (the
+        // same operations on the same operands as below) and the cells look them up.
+        float *const tab = (float *)tp;      // [COLS][21], in the space of the staged columns (not staged on this path)
+        static_assert(COLS * 21 <= (COLS + 1) * STR * 2, "score table must fit the column staging area");
+        __shared__ float As[32];
+        const uint32_t fb0 = 4u * blockIdx.y + threadIdx.x / PGM_ROWS;
+        const uint32_t fl = threadIdx.x % PGM_ROWS;
+        const bool active = fb0 < J.nb;
+        int sym = 20;
+        bool plain = true;
+        float a_row = 0.f;
+        if (active) {
+            const uint32_t y = PGM_ROWS * fb0 + fl;
+            const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
+            const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
+            int nz = 0;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const float4 v = src[q];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (vv[u] != 0.0f) { ++nz; sym = 4 * q + u; plain = plain && vv[u] == 1.0f; }
+            }
+            plain = plain && nz <= 1;
+            a_row = J.a1[yc];
+        }
+        if (threadIdx.x < 32) As[threadIdx.x] = 0.f;
+        if (__syncthreads_and(plain ? 1 : 0)) {
+            if (active) As[sym] = a_row;   // (rows with the same content have the same a1: any of them writes it)
+            __syncthreads();
+            const float mi = J.sc.match_init;
+            constexpr int NE = (COLS * 21 + 4 * PGM_ROWS - 1) / (4 * PGM_ROWS);   // table entries per thread: all loads first
+            float tt[NE], tb2[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int i = (int)threadIdx.x + e * 4 * PGM_ROWS;
+                const int ci = i / 21, k = i % 21, c = cbase + ci;
+                const bool in = i < COLS * 21 && c >= 0 && c <= (int)J.ncol;
+                tb2[e] = in ? J.b2[c] : 0.f;
+                tt[e] = (in && k < 20) ? J.t2[(size_t)DP * c + k] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int i = (int)threadIdx.x + e * 4 * PGM_ROWS;
+                if (i < COLS * 21) tab[i] = pgm_emission_finish(0.0f + tt[e], As[i % 21], tb2[e], mi);
+            }
+            __syncthreads();
+            if (!active) return;
+            PGM_GLOBAL pgm_v4f *const Sq = (PGM_GLOBAL pgm_v4f *)(uintptr_t)J.S;
+            const int l = PGM_HALO + (int)fl;
+#pragma unroll 1
+            for (int w = 0; w < PGM_EM_TB; ++w) {
+                const uint32_t tb = tb0 + w;
+                if (tb >= J.nblk) break;
+                float out[PGM_BLOCK];
+#pragma unroll
+                for (int i = 0; i < PGM_BLOCK; ++i) out[i] = tab[((int)(tb * PGM_BLOCK) + i - l - cbase) * 21 + sym];
+                PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)fb0 * J.nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
+#pragma unroll
+                for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
+            }
+            return;
+        }
+    }
     // one float4 load per (column, 4 k): the value T[c][k] is the low half of pair c and the high half of pair c - 1
     const float4 *t2q = (const float4 *)J.t2;
     float *tpf = (float *)tp;

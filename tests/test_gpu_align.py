@@ -27,6 +27,8 @@ def _cmp_job(batch, idx, job, res):
 
 FAMILIES = [
     dict(skip_frac=0.0, drop_chain_frac=0.0),                 # pure chains (leaf vs leaf)
+    dict(skip_frac=0.0, drop_chain_frac=0.0, onehot_frac=1.0),   # ... with one-hot rows throughout: the emission kernel's score table per (symbol, column)
+    dict(skip_frac=0.1, onehot_frac=0.97),                    # almost one-hot: workgroups with and without other rows
     dict(skip_frac=0.2),                                      # merged-graph like skip edges: near window + LDS history
     dict(skip_frac=0.3, repeat_frac=0.05),                    # + tandem-repeat edges
     dict(skip_frac=0.4, skip_span=3, skip_max=2),             # only near predecessors (distance 2 and 3): the register window alone
