@@ -14,7 +14,9 @@ VARIANTS = [dict(x.split("=") for x in v.split(",") if x) for v in os.environ.ge
 for rep, var in enumerate(VARIANTS * 2):
     env = dict(os.environ, PGM_HOST_PROFILE="1", **var)
     print("==== variant", var)
+    import time
+    t_wall = time.time()
     r = subprocess.run([pg.PGMSA_PATH, "--fasta"] + extra + (["-t", os.path.join(ROOT, "tests/golden", tree)] if tree else []) + ["--stats", "-o", os.path.join(tmp, "o.fa"), fa],
                        capture_output=True, text=True, env=env)
-    print("---- rep", rep, "rc", r.returncode)
+    print("---- rep", rep, "rc", r.returncode, "wall %.1f ms" % ((time.time() - t_wall) * 1e3))
     print(r.stderr)
