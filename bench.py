@@ -163,6 +163,10 @@ def main():
         # product): the best of three by progressive_s, all three listed (a pass is 50-150 ms, and this pool's hosts stall a GPU
         # wait for ~20 ms about once a second — on some boxes several times per pass: DESIGN §4)
         runs = []
+        if rank != 0:   # (only rank 0 reports the driver's times)
+            st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+            st["wall_s"] = None
+            return js, st, hashlib.md5(r.stdout.encode()).hexdigest()
         for _ in range(3):
             t0 = time.time()
             r2 = subprocess.run([pg.PGMSA_PATH] + flags + ["--stats", fa], capture_output=True, text=True, env=env)
