@@ -74,7 +74,7 @@ static std::mutex g_pinned_mu;
 static std::unordered_set<void *> g_pinned_registered;
 static hipError_t pinned_alloc(size_t bytes, void **out) {
     const size_t H = (size_t)2 << 20, len = (std::max<size_t>(bytes, 1) + H - 1) / H * H;
-    void *p = aligned_alloc(H, len);
+    void *p = getenv("PGM_PINNED_MALLOC") ? nullptr : aligned_alloc(H, len);
     if (p) {
         (void)madvise(p, len, MADV_HUGEPAGE);
         (void)lib_pool().run(len / H, len >= 8 * H ? 16u : 1u, [&](size_t c) { for (size_t o = 0; o < H; o += 4096) ((volatile char *)p)[c * H + o] = 0; });
