@@ -105,6 +105,14 @@ int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                            const pgm_graph *const *g2, const pgm_model *const *model,
                            const pgm_scores *scores, pgm_align_batch **out);
+/* The same with flags.  PGM_BATCH_KEEP_MATRICES: every job's M, X, Y, W matrices are written to device memory so that
+ * pgm_align_batch_read_matrices can return them (test hook).  Without it a job of two plain chains (sequence graph against
+ * sequence graph) keeps one decision byte per cell instead of the 16 bytes of the four floats: its traceback walks the
+ * decisions the fill took with the operands in registers (same tie rules, GraphAlign.h:382-411), the mappings are the same. */
+#define PGM_BATCH_KEEP_MATRICES 1u
+int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
+                              const pgm_graph *const *g2, const pgm_model *const *model,
+                              const pgm_scores *scores, uint32_t flags, pgm_align_batch **out);
 int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b);
 int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out);
 void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);

@@ -11,11 +11,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpgm_hip.so")
+# (PGM_TOOLS_LIB=1: the tools build of the same library, `make -C prographmsa_amd/csrc tools` — experiment switches compiled in)
+LIB_PATH = os.path.join(_HERE, "lib", "libpgm_hip_tools.so" if os.environ.get("PGM_TOOLS_LIB") else "libpgm_hip.so")
 PGMSA_PATH = os.path.join(_HERE, "bin", "pgmsa")
 
 PGM_OK, PGM_ERR_INVALID, PGM_ERR_DEVICE, PGM_ERR_BACKTRACK, PGM_ERR_NOMEM = 0, 1, 2, 3, 4
 PGM_GAP = 0xFFFFFFFF
+PGM_BATCH_KEEP_MATRICES = 1
 
 
 class pgm_graph(C.Structure):
@@ -53,7 +55,7 @@ class pgm_align_out(C.Structure):
 # every symbol include/pgm_hip.h declares
 EXPORTS = [
     "pgm_device_count", "pgm_ctx_create", "pgm_ctx_destroy", "pgm_last_error", "pgm_ctx_device_info",
-    "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_run", "pgm_align_batch_fetch",
+    "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_last_kernel_ms", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_dist_last_kernel_ms",
@@ -76,6 +78,7 @@ def _load():
         "pgm_ctx_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
         "pgm_align_graphs_batch": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), C.POINTER(pgm_align_out)]),
         "pgm_align_batch_create": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), C.POINTER(vp)]),
+        "pgm_align_batch_create_ex": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), u32, C.POINTER(vp)]),
         "pgm_align_batch_run": (C.c_int, [vp, vp]),
         "pgm_align_batch_fetch": (C.c_int, [vp, vp, C.POINTER(pgm_align_out)]),
         "pgm_align_batch_destroy": (None, [vp, vp]),

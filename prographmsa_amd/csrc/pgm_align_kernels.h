@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
 
 // ---------------------------------------------------------------------------------------------
 // cell addressing (see PgmJob): cell = float4 {M, X, W, Y}
+// (R = 1 << J.rshift rows per lane: band b = y / (64 R), lane l = (y % (64 R)) / R, r = y % R)
 __device__ __forceinline__ size_t pgm_cell_index(const PgmJob &J, uint32_t y, uint32_t x) {
-    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS);
-    return ((size_t)b * J.tsteps + (x + l)) * 64u + l;
+    const uint32_t sh = J.rshift, b = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & ((1u << sh) - 1u);
+    return ((((size_t)b * J.tsteps + (x + l)) << sh) | r) * 64u + l;
 }
 __device__ __forceinline__ float4 pgm_load_cell(const PgmJob &J, uint32_t y, uint32_t x) {
     return J.cells[pgm_cell_index(J, y, x)];
@@ -179,7 +180,12 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     __shared__ float bq[COLS];
     const PgmJob &J = jobs[blockIdx.z];
     const uint32_t tb0 = blockIdx.x * PGM_EM_TB;
-    if (tb0 >= J.nblk || 4u * RB * blockIdx.y >= J.nb) return;
+    // R rows per lane (PgmJob::rshift): the kernel's "bands" are the nb R virtual bands v = b R + r (lane l of virtual band v
+    // owns row 64 R b + R l + r, at step t column t - l as ever); scores land at [(b nblk + tb) R + r][lane][8]
+    const uint32_t rsh = J.rshift, nvb = J.nb << rsh;
+    if (tb0 >= J.nblk || 4u * RB * blockIdx.y >= nvb) return;
+    auto row_of = [&](uint32_t v, uint32_t lane_) { return ((((v >> rsh) << 6) + lane_) << rsh) | (v & ((1u << rsh) - 1u)); };
+    auto sblock_of = [&](uint32_t v, uint32_t tb_) { return ((((size_t)(v >> rsh) * J.nblk + tb_) << rsh) | (v & ((1u << rsh) - 1u))); };
     const uint32_t t0 = tb0 * PGM_BLOCK;
     const int cbase = (int)t0 - 63;
     if (DP == 20 && RB == 1) {
@@ -193,12 +199,12 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
         __shared__ float As[32];
         const uint32_t fb0 = 4u * blockIdx.y + threadIdx.x / PGM_ROWS;
         const uint32_t fl = threadIdx.x % PGM_ROWS;
-        const bool active = fb0 < J.nb;
+        const bool active = fb0 < nvb;
         int sym = 20;
         bool plain = true;
         float a_row = 0.f;
         if (active) {
-            const uint32_t y = PGM_ROWS * fb0 + fl;
+            const uint32_t y = row_of(fb0, fl);
             const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
             const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
             int nz = 0;
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
                 float out[PGM_BLOCK];
 #pragma unroll
                 for (int i = 0; i < PGM_BLOCK; ++i) out[i] = tab[((int)(tb * PGM_BLOCK) + i - l - cbase) * 21 + sym];
-                PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)fb0 * J.nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
+                PGM_GLOBAL pgm_v4f *dst = Sq + (sblock_of(fb0, tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
 #pragma unroll
                 for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]};
             }
@@ -273,11 +279,11 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     __syncthreads();
     const uint32_t b0 = (4u * blockIdx.y + threadIdx.x / PGM_ROWS) * RB;   // this thread's bands: b0 .. b0 + RB - 1 (same lane, same columns)
     const int l = PGM_HALO + (int)(threadIdx.x % PGM_ROWS);
-    if (b0 >= J.nb) return;
+    if (b0 >= nvb) return;
     float gy[RB][DP], ay[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-        const uint32_t y = PGM_ROWS * (b0 + (uint32_t)r) + (uint32_t)(l - PGM_HALO);
+        const uint32_t y = row_of(b0 + (uint32_t)r, (uint32_t)(l - PGM_HALO));
         const uint32_t yc = (y + 1 < J.n1) ? y : 0u;
         const float4 *src = (const float4 *)(J.g1f + (size_t)DP * yc);
 #pragma unroll
@@ -319,8 +325,8 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            if (b0 + (uint32_t)r < J.nb) {
-                PGM_GLOBAL pgm_v4f *dst = Sq + (((size_t)(b0 + (uint32_t)r) * nblk + tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
+            if (b0 + (uint32_t)r < nvb) {
+                PGM_GLOBAL pgm_v4f *dst = Sq + (sblock_of(b0 + (uint32_t)r, tb) * 64u + (uint32_t)l) * (PGM_BLOCK / 4);
 #pragma unroll
                 for (int q = 0; q < PGM_BLOCK / 4; ++q) dst[q] = pgm_v4f{out[r][4 * q], out[r][4 * q + 1], out[r][4 * q + 2], out[r][4 * q + 3]};
             }
@@ -440,8 +446,8 @@ __device__ static void pgm_mark_alternative_path(const PgmJob &J, uint32_t start
 
 // S(y,x) as the emission kernel stored it (skewed order, see PgmJob::S): one load instead of recomputing the dot product
 __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, uint32_t x) {
-    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS), t = x + l;
-    return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
+    const uint32_t sh = J.rshift, b = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & ((1u << sh) - 1u), t = x + l;
+    return J.S[(((((size_t)b * J.nblk + (t / PGM_BLOCK)) << sh) | r) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
 }
 
 #ifndef PGM_POLL_PREFETCH
@@ -472,6 +478,25 @@ struct PgmPredView {
     bool lds;
     uint32_t base;     // LDS: slot * PGM_TB_PK; memory: first entry index
 };
+
+// Mappings of a finished walk: reversed into alignment order (GraphAlign.h:520-521) by all threads of the worker, straight
+// into the pinned host block (posted PCIe writes, 1 KB per wavefront-iteration), then the result record, status word last: a
+// host that copies finished jobs while the kernel is still running (pgm_align_batch_fetch) polls that word.
+__device__ static void pgm_traceback_publish(const PgmJob &J, const uint32_t len, const int tid, const int nthreads) {
+    for (uint32_t i = (uint32_t)tid; i < len; i += (uint32_t)nthreads) {
+        const uint32_t j = len - 1 - i;
+        J.hmap1[i] = J.map1[j];
+        J.hmap2[i] = J.map2[j];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const PgmJob::Result r = *J.result;
+        J.hresult->score = r.score; J.hresult->n_tr_indels = r.n_tr_indels; J.hresult->len = r.len;
+        __threadfence_system();
+        __hip_atomic_store(&J.hresult->status, r.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads, unsigned long long *stat) {
     constexpr uint32_t TT = PGM_TB_T;
@@ -981,27 +1006,10 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         }
         __syncthreads();                // "request" that ends the loaders' loop
     }
-    // reverse the two mappings (GraphAlign.h:520-521), all threads; thread 0's pushes are ordered by the barrier.  The
-    // reversed copy goes straight to the pinned host block (posted PCIe writes, 1 KB per wavefront-iteration), so the
-    // host needs no device-to-host copy after the kernel.
+    // reverse the two mappings (GraphAlign.h:520-521), all threads; thread 0's pushes are ordered by the barrier
     __threadfence_block();
     __syncthreads();
-    const uint32_t len = T.len;
-    for (uint32_t i = (uint32_t)tid; i < len; i += (uint32_t)nthreads) {
-        const uint32_t j = len - 1 - i;
-        J.hmap1[i] = J.map1[j];
-        J.hmap2[i] = J.map2[j];
-    }
-    // the record announces the mappings to a host that copies finished jobs while the kernel is still running
-    // (pgm_align_batch_fetch polls `status`): mappings first, then score / counts / length, the status word last
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-        const PgmJob::Result r = *J.result;
-        J.hresult->score = r.score; J.hresult->n_tr_indels = r.n_tr_indels; J.hresult->len = r.len;
-        __threadfence_system();
-        __hip_atomic_store(&J.hresult->status, r.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    pgm_traceback_publish(J, T.len, tid, nthreads);
 }
 
 #define PGM_SPIN_LIMIT (1u << 24)
@@ -1471,6 +1479,429 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
     if (lane == 0 && !stall) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lean sweep of a CHAIN-ONLY job (PgmJob::lean: both graphs are plain chains 0 -> 1 -> ... -> n-1 with finite edge costs — a
+// sequence graph against a sequence graph: the leaf level of the guide tree, half of the cells of a progressive pass;
+// GraphAlign.h:212-260 with one-entry predecessor lists).  Same recurrence, same float operations in the same order as
+// pgm_sweep_band<0>; what differs is the schedule and what is kept:
+//   * a lane owns R consecutive rows (a band = 64 R rows): only its first row takes W / Y of the row above from the lane above
+//     (two DPP shifts per step), the others from the lane's own registers, and the column's edge cost travels down the lanes
+//     with the column (one more shift) — no LDS on the step's path at all;
+//   * ONE worker sweeps the whole job: wavefront w takes the bands w, w + 8, ..., and the last row of a band reaches the band
+//     below through an LDS ring of {W, Y} per column (lane 63 writes it, lanes 0-7 of the consumer read a block of eight
+//     columns) with two LDS counters per ring: columns produced / columns consumed (the producer never runs more than the ring
+//     ahead of its consumer).  No hand-off through memory, no progress words, no virtual lanes: the band below follows
+//     64 + 8 steps behind, whatever the memory system is doing;
+//   * the traceback's decisions are taken HERE, where the operands are in registers: four bits per cell (PgmJob::codes)
+//       bit 3 / 2  W equals M / W equals Y: the state of a walk that arrives at this cell through W is M, else Y, else X — the
+//                  reference's order of tests (GraphAlign.h:400-411)
+//       bit 1 / 0  the X / Y state of this cell came from an opening (W + gap_init), not from an extension: the reference's
+//                  walk takes the extension unless the opening recomputes the stored value strictly better (:382-392,
+//                  :421-431), i.e. — max(a, b) - c being max(a - c, b - c) exactly — unless (a - c) differs from the stored
+//                  value.  (Row 0 / column 0 were filled with start_gap and are re-evaluated with gap_init by the walk; there
+//                  either decision leads to the same next cell in the same state, so the bit is never looked at.)
+//     and pgm_traceback_chain walks the codes.  The four float matrices go to memory only if the caller wants to read them
+//     (KEEP: pgm_align_batch_create_ex with PGM_BATCH_KEEP_MATRICES, the test hook); the END node's one predecessor cell
+//     (n1-2, n2-2) is always left in PgmJob::endcell.
+// Cells go out as R coalesced 1 KB runs per step, cells[((b tsteps + t) R + r) 64 + lane] (PgmJob::rshift); codes as one
+// 32-bit word per lane, row and block of eight steps (step i of the block in bits 31-4i .. 28-4i),
+// codes[((b nblk + t / 8) R + r) 64 + lane].
+#define PGM_LEAN_RING 512   // columns per ring (4 KB per wavefront)
+template <int R, bool KEEP>
+__device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave, const int lane, uint8_t *pool, int *lsync_generic,
+                                                int *abort_flag, bool &aborted, const uint32_t spin_limit) {
+    constexpr int BL = PGM_BLOCK, RING = PGM_LEAN_RING;
+    typedef __attribute__((address_space(3))) int pgm_lds_int;
+    typedef float pgm_v2f __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) pgm_v2f pgm_lds_f2;
+    typedef uint32_t pgm_v4u __attribute__((ext_vector_type(4)));
+    pgm_lds_int *P = (pgm_lds_int *)lsync_generic, *Cn = P + 8;   // columns produced by wavefront w / consumed by wavefront w (cumulative over its bands)
+    const int prod = (wave + 7) & 7, cons = (wave + 1) & 7;
+    pgm_lds_f2 *ring_out = (pgm_lds_f2 *)pool + wave * RING, *ring_in = (pgm_lds_f2 *)pool + prod * RING;
+    const uint32_t n1 = J.n1, ncol = J.ncol, tsteps = J.tsteps, nb = J.nb, nblk = J.nblk;
+    const float ge = J.sc.gap_extend, gi = J.sc.gap_init, sg = J.sc.start_gap, s_init = J.sc.start_init;
+    const float4 *ni2q = (const float4 *)J.ni2;
+    // the END node's predecessor cell (n1-2, n2-2): band, lane, row of the lane, step (all wave-uniform)
+    const uint32_t ye = n1 - 2u, be = ye / (64u * R), le = (ye % (64u * R)) / R, re = ye % R, te = (ncol - 1u) + le;
+    uint32_t q = 0;
+    for (uint32_t b = (uint32_t)wave; b < nb && !aborted; b += PGM_WAVES, ++q) {
+        const uint32_t y0 = (64u * b + (uint32_t)lane) * (uint32_t)R;
+        float ccy[R], gox[R];
+        uint32_t soff[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t y = y0 + (uint32_t)r;
+            const bool valid = y + 1 < n1;
+            ccy[r] = pgm_gload4((const float4 *)(J.ni1 + (valid ? y : 0u))).x;   // (+inf for START and for the rows below the matrix)
+            gox[r] = (valid && y == 0) ? sg : gi;
+            // (a row below the matrix: 0x40000000, a step outside the columns: 0x80000000 — any sum of the two lies beyond the
+            //  band's num_records, which the host keeps below 1 GiB, and the buffer range check drops the store)
+            soff[r] = valid ? (uint32_t)lane * 16u + (uint32_t)r * 1024u : 0x40000000u;
+        }
+        const bool origin = b == 0 && lane == 0;   // this lane's first row is row 0: W(0,0) = start_init
+        const bool has_prev = b > 0, has_next = b + 1 < nb;
+        const uint32_t pbase = q * ncol, cbase = (wave == 0 ? q - 1u : q) * ncol;
+        const __amdgpu_buffer_rsrc_t rsrc = pgm_band_rsrc(J.cells + (KEEP ? (size_t)b * tsteps * (64u * R) : (size_t)0), KEEP ? tsteps * (1024u * R) : 16u);
+        PGM_GLOBAL uint32_t *codes_band = (PGM_GLOBAL uint32_t *)(uintptr_t)(J.codes + (size_t)b * nblk * (64u * R)) + lane;
+        const float4 *S_band = (const float4 *)J.S + (size_t)b * nblk * (uint32_t)(R * 64 * (BL / 4));
+        // prefetch, a SUPER-BLOCK of 16 steps ahead (a block ahead does not cover the memory latency once the steps are this
+        // short): emission scores (R x 16 per lane) and, in every lane l, the chain cost of column T0 + (l & 15) (column 0 has
+        // no predecessor; its cost is never looked at with a finite left operand: 0 stands in)
+        float4 pfs[R][2 * BL / 4];
+        float pfc = 0.f;
+        auto load_s_super = [&](uint32_t tb) {   // blocks tb, tb + 1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t tbh = min(tb + (uint32_t)h, nblk - 1u);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < BL / 4; ++k) pfs[r][h * (BL / 4) + k] = pgm_gload4(S_band + ((size_t)(tbh * R + r) * 64u + (uint32_t)lane) * (BL / 4) + k);
+            }
+        };
+        auto load_c_super = [&](uint32_t c0) {
+            const uint32_t col = c0 + (uint32_t)(lane & 15);
+            float v = 0.f;
+            if (col != 0 && col < ncol) v = pgm_gload4(ni2q + 5u * col).x;
+            pfc = v;
+        };
+        float Sc[R][2 * BL];
+        auto take_super = [&]() {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < 2 * BL / 4; ++k) { Sc[r][4 * k] = pfs[r][k].x; Sc[r][4 * k + 1] = pfs[r][k].y; Sc[r][4 * k + 2] = pfs[r][k].z; Sc[r][4 * k + 3] = pfs[r][k].w; }
+        };
+        load_s_super(0);
+        load_c_super(0);
+        take_super();
+        float cblk = pfc;
+        load_s_super(2);
+        load_c_super(2 * BL);
+        float W_left[R], X_left[R];
+        uint32_t cw[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { W_left[r] = PGM_NEG_INF; X_left[r] = PGM_NEG_INF; cw[r] = 0u; }
+        float W_diag0 = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF, ccx_o = 0.f;
+        int p_seen = has_prev ? 0 : 0x7fffffff, c_seen = has_next ? 0 : 0x7fffffff;
+        // one block of eight steps (hc: first / second half of the super-block)
+        auto block = [&](const uint32_t t0, auto hc) {
+            constexpr int H = decltype(hc)::value;
+            // ---- the eight columns of the row above this band that lane 0 meets in this block (every lane l holds column t0 + (l & 7)) ----
+            float inW = PGM_NEG_INF, inY = PGM_NEG_INF;
+            if (has_prev) {
+                const int need = (int)(cbase + min(t0 + (uint32_t)BL, ncol));
+                uint32_t spins = 0;
+                while (p_seen < need) {
+                    p_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(P + prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (p_seen >= need) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit || ((spins & 1023u) == 0u && __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                        break;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                const uint32_t col = t0 + (uint32_t)(lane & 7);
+                const pgm_v2f v = ring_in[(cbase + min(col, ncol - 1u)) & (uint32_t)(RING - 1)];
+                if (col < ncol) { inW = v.x; inY = v.y; }
+                asm volatile("" ::: "memory");
+                // (LDS operations of a wavefront execute in order: the producer sees the counter after the reads above were served)
+                __hip_atomic_store(Cn + wave, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (has_next && t0 + (uint32_t)BL > 63u) {
+                // lane 63 writes the columns t0 - 63 .. t0 - 56 of this band's last row in this block: their ring slots must be free
+                const int need = (int)(pbase + min(t0 + (uint32_t)BL - 63u, ncol)) - RING;
+                uint32_t spins = 0;
+                while (c_seen < need) {
+                    c_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(Cn + cons, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (c_seen >= need) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > spin_limit || ((spins & 1023u) == 0u && __hip_atomic_load((const PGM_GLOBAL int *)(uintptr_t)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store((PGM_GLOBAL int *)(uintptr_t)abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        aborted = true;
+                        break;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+            // ec: the block in which the END node's predecessor cell is computed (its store is compiled into that variant only)
+            auto step = [&](auto ic, auto ec) {
+                constexpr int i = decltype(ic)::value;
+                constexpr bool ENDBLK = decltype(ec)::value;
+                const uint32_t t = t0 + (uint32_t)i;
+                const int xs = (int)t - lane;
+                // lane 0's inputs of this step: the block registers rotate one lane down per step within their row of 16 lanes
+                // (row_ror:15), so lane 0 holds those of the current step; the other lanes receive what the lane above produced in
+                // the previous step (wave_shr:1)
+                auto rot = [&](float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x12F, 0xf, 0xf, false)); };
+                const float ccx = pgm_dpp_wave_shr1(ccx_o, cblk);
+                const float W_up0 = pgm_dpp_wave_shr1(W_o, inW);
+                const float Y_up0 = pgm_dpp_wave_shr1(Y_o, inY);
+                if (H == 0 || i + 1 < BL) cblk = rot(cblk);
+                if (i + 1 < BL) { inW = rot(inW); inY = rot(inY); }
+                const float gopen_y = (xs == 0) ? sg : gi;
+                uint32_t toff = 0u;
+                if (KEEP) toff = ((uint32_t)xs < ncol) ? t * (1024u * R) : 0x80000000u;
+                float W_up = W_up0, Y_up = Y_up0, W_dg = W_diag0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_dg, Sc[r][H * BL + i]), ccy[r]), ccx);
+                    const float ax = __fadd_rn(X_left[r], ge), ay = __fadd_rn(Y_up, ge);
+                    const float Xv = __fsub_rn(fmaxf(ax, __fadd_rn(W_left[r], gox[r])), ccx);
+                    const float Yv = __fsub_rn(fmaxf(ay, __fadd_rn(W_up, gopen_y)), ccy[r]);
+                    float Wv = fmaxf(Mv, fmaxf(Xv, Yv));
+                    // the walk's decisions at this cell (see above): each comparison shifts one bit into the block's word
+                    uint32_t w = (i == 0) ? 0u : cw[r];
+                    w = w + w + ((Wv == Mv) ? 1u : 0u);
+                    w = w + w + ((Wv == Yv) ? 1u : 0u);
+                    w = w + w + ((__fsub_rn(ax, ccx) != Xv) ? 1u : 0u);
+                    w = w + w + ((__fsub_rn(ay, ccy[r]) != Yv) ? 1u : 0u);
+                    cw[r] = w;
+                    if (i == 0 && r == 0) { if (origin && t == 0u) Wv = s_init; }   // (xs == 0 in lane 0 only at the band's very first step)
+                    if (KEEP) {
+                        pgm_v4u cv;
+                        cv.x = __float_as_uint(Mv); cv.y = __float_as_uint(Xv); cv.z = __float_as_uint(Wv); cv.w = __float_as_uint(Yv);
+                        __builtin_amdgcn_raw_buffer_store_b128(cv, rsrc, soff[r] + toff, 0, 16);
+                    }
+                    if (ENDBLK) {
+                        if (t == te && (uint32_t)r == re && (uint32_t)lane == le) *(PGM_GLOBAL pgm_v4f *)(uintptr_t)J.endcell = pgm_v4f{Mv, Xv, Wv, Yv};
+                    }
+                    W_dg = W_left[r];
+                    W_left[r] = Wv; X_left[r] = Xv;
+                    W_up = Wv; Y_up = Yv;
+                    if (i == BL - 1) codes_band[(size_t)((t0 / BL) * R + r) * 64u] = w;
+                }
+                W_diag0 = W_up0;
+                W_o = W_up; Y_o = Y_up; ccx_o = ccx;
+                if (has_next) {   // lane 63 completes column t - 63 of the band's last row: slot and validity are wave-uniform
+                    const uint32_t xc = t - 63u;
+                    if (xc < ncol) {
+                        const uint32_t slot = (pbase + xc) & (uint32_t)(RING - 1);
+                        if (lane == 63) ring_out[slot] = pgm_v2f{W_up, Y_up};
+                    }
+                }
+            };
+            static_assert(BL == 8, "eight steps per block");
+            if (b == be && (te & ~(uint32_t)(BL - 1)) == t0) {
+                constexpr std::true_type E{};
+                step(std::integral_constant<int, 0>{}, E); step(std::integral_constant<int, 1>{}, E); step(std::integral_constant<int, 2>{}, E); step(std::integral_constant<int, 3>{}, E);
+                step(std::integral_constant<int, 4>{}, E); step(std::integral_constant<int, 5>{}, E); step(std::integral_constant<int, 6>{}, E); step(std::integral_constant<int, 7>{}, E);
+            } else {
+                constexpr std::false_type E{};
+                step(std::integral_constant<int, 0>{}, E); step(std::integral_constant<int, 1>{}, E); step(std::integral_constant<int, 2>{}, E); step(std::integral_constant<int, 3>{}, E);
+                step(std::integral_constant<int, 4>{}, E); step(std::integral_constant<int, 5>{}, E); step(std::integral_constant<int, 6>{}, E); step(std::integral_constant<int, 7>{}, E);
+            }
+            if (has_next) {
+                asm volatile("" ::: "memory");
+                const int done = (int)t0 + BL - 63;   // columns of the last row complete after this block
+                if (done > 0) __hip_atomic_store(P + wave, (int)(pbase + min((uint32_t)done, ncol)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        for (uint32_t T0 = 0; T0 < tsteps && !aborted; T0 += 2 * BL) {
+            block(T0, std::integral_constant<int, 0>{});
+            if (T0 + (uint32_t)BL < tsteps && !aborted) block(T0 + (uint32_t)BL, std::integral_constant<int, 1>{});
+            // next super-block's operands (loaded a super-block ago), then the loads of the one after it
+            const uint32_t T1 = T0 + 2 * BL;
+            if (T1 >= tsteps) break;
+            take_super();
+            cblk = pfc;
+            load_s_super(T1 / BL + 2u);
+            load_c_super(T1 + 2 * BL);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // codes (and cells) of this wavefront's bands are on their way before the worker's traceback starts
+}
+
+// Traceback of a lean job (GraphAlign.h:264-521 for two chains): wavefront 0 of the worker walks the decision bits the sweep
+// left (see pgm_sweep_chain): state M goes to (y-1, x-1), a gap state to (y-1, x) / (y, x-1) and stays in the gap state
+// unless the cell's opening bit is set; the state after a W source is read from the destination's bits 3-2.
+// An alignment path is mostly diagonal runs, and a run needs no walker: lane k looks at the cell k + 1 steps up the diagonal,
+// one ballot finds the first cell the walk does not enter in state M, the lanes before it write their mapping entries at once.
+// Only the cells between runs (gaps) are walked one at a time.  The codes around the walker — the 128 steps of its band that
+// end at its position: 16 words per lane and row — are staged in LDS by the walking wavefront itself; the 128 steps before
+// them are requested at the same time and arrive while it walks (only a change of band is not foreseen).  Mapping entries
+// are collected in LDS and go out in blocks.
+template <int R>
+__device__ static void pgm_traceback_chain(const PgmJob &J, uint8_t *pool, uint32_t *len_lds, const int tid, const int nthreads, unsigned long long *stat) {
+    constexpr int WB = 16, NW = WB * R;          // window: WB blocks of 8 steps x R rows x 64 lanes, one word each
+    constexpr uint32_t MB = 2048u;
+    const uint32_t n1 = J.n1, n2 = J.n2, nblk = J.nblk;
+    if (tid < 64) {
+        const int lane = tid;
+        typedef __attribute__((address_space(3))) uint32_t pgm_lds_u32;
+        pgm_lds_u32 *win = (pgm_lds_u32 *)pool;                       // [2][NW][64]
+        pgm_lds_u32 *mb1 = win + 2 * NW * 64, *mb2 = mb1 + MB;       // mapping entries not yet written out
+        const PGM_GLOBAL uint32_t *codes = (const PGM_GLOBAL uint32_t *)(uintptr_t)J.codes;
+        const pgm_scores s = J.sc;
+        int status = PGM_OK;
+        enum { State_m = 0, State_x = 1, State_y = 2 };
+        int state = State_m;
+        uint32_t y = n1 - 1, x = n2 - 1, len = 0, flushed = 0;
+        auto flush = [&](uint32_t keep_room) {   // (LDS operations of a wavefront execute in order)
+            if (len - flushed + keep_room <= MB) return;
+            for (uint32_t i = (uint32_t)lane; i < len - flushed; i += 64u)
+                if (flushed + i < n1 + n2) { J.map1[flushed + i] = mb1[i]; J.map2[flushed + i] = mb2[i]; }
+            flushed = len;
+        };
+        auto push = [&](uint32_t a, uint32_t c) {
+            flush(1u);
+            if (lane == 0) { mb1[len - flushed] = a; mb2[len - flushed] = c; }
+            ++len;
+        };
+        // ---- END node (GraphAlign.h:264-280 and the first step of the walk, :300-350): one predecessor pair ----
+        const float yv = J.tb1[n1 - 1].v[0], xv = J.tb2[n2 - 1].v[0];
+        const uint32_t yp = n1 - 2, xp = n2 - 2;
+        float Wend = PGM_NEG_INF;
+        push(n1 - 1, n2 - 1);
+        {
+            const float4 c = (yp | xp) != 0u ? pgm_gload4(J.endcell) : make_float4(PGM_NEG_INF, PGM_NEG_INF, s.start_init, PGM_NEG_INF);   // {M, X, W, Y}
+            if ((yp | xp) == 0u) {
+                Wend = fmaxf(__fsub_rn(__fsub_rn(s.end_skip, yv), xv), Wend);
+            } else {
+                Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv), Wend);
+                Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv), Wend);
+                Wend = fmaxf(__fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv), Wend);
+            }
+            float best = INFINITY;
+            bool found = false;
+            float d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.x, s.end_match), yv), xv)));
+            if (best > d) { best = d; state = State_m; found = true; }
+            d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.w, s.end_gap), yv), xv)));
+            if (best > d) { best = d; state = State_y; found = true; }
+            d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(__fadd_rn(c.y, s.end_gap), yv), xv)));
+            if (best > d) { best = d; state = State_x; found = true; }
+            d = fabsf(__fsub_rn(Wend, __fsub_rn(__fsub_rn(s.end_skip, yv), xv)));
+            if ((yp | xp) == 0u && best > d) { best = d; found = true; }
+            if (!found) status = PGM_ERR_BACKTRACK;
+            // (the same in every lane; said explicitly so that the walk below is scalar code)
+            state = __builtin_amdgcn_readfirstlane(state);
+            status = __builtin_amdgcn_readfirstlane(status);
+            y = yp; x = xp;
+            if ((x | y) != 0u) push(state == State_x ? 0xFFFFFFFFu : y, state == State_y ? 0xFFFFFFFFu : x);
+        }
+        // ---- code windows: blocks wq0 - WB + 1 .. wq0 of band wb ----
+        int wb = -1, wq0 = -1, cur = 0, pf_b = -1, pf_q0 = -1;
+        uint32_t pf[NW];
+        auto issue = [&](int b, int q0) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int qq = max(q0 - (WB - 1) + k / R, 0);
+                pf[k] = codes[((size_t)((uint32_t)b * nblk + (uint32_t)qq) * R + (uint32_t)(k % R)) * 64u + (uint32_t)lane];
+            }
+            pf_b = b; pf_q0 = q0;
+        };
+        auto land = [&]() {                 // the requested window becomes the current one
+            cur ^= 1;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) win[(cur * NW + k) * 64 + lane] = pf[k];
+            wb = pf_b; wq0 = pf_q0;
+        };
+        unsigned long long st_win = 0, st_nwin = 0, st_miss = 0, st_iter = 0;   // timeline build only
+        auto need_window = [&](uint32_t yy, uint32_t xx) {   // (wave-uniform arguments) the window that holds cell (yy, xx)
+            const int b = (int)(yy / (64u * R)), qw = (int)((xx + (yy % (64u * R)) / R) >> 3);
+            if (b != wb || qw > wq0 || qw < wq0 - (WB - 1)) {
+                const unsigned long long r0 = stat ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                if (pf_b != b || qw > pf_q0 || qw < pf_q0 - (WB - 1)) { issue(b, qw); ++st_miss; }
+                land();
+                if (wq0 >= WB) issue(wb, wq0 - WB);   // what the walk needs next unless it changes band
+                if (stat) { st_win += __builtin_amdgcn_s_memrealtime() - r0; ++st_nwin; }
+            }
+        };
+        auto code_of = [&](uint32_t yy, uint32_t xx, bool &inwin) -> uint32_t {   // per-lane cell; inwin: its word is in the current window
+            const uint32_t b = yy / (64u * R), l = (yy % (64u * R)) / R, r = yy % R, t = xx + l;
+            const int qw = (int)(t >> 3);
+            inwin = (int)b == wb && qw <= wq0 && qw >= wq0 - (WB - 1);
+            const uint32_t w = win[(cur * NW + (inwin ? (qw - (wq0 - (WB - 1))) * R + (int)r : 0)) * 64 + (int)l];
+            return (w >> (28u - 4u * (t & 7u))) & 15u;
+        };
+        auto state_of = [](uint32_t code) { return (code & 8u) ? 0 : ((code & 4u) ? 2 : 1); };   // M, else Y, else X
+        uint32_t code_cur = 0u;
+        if ((x | y) != 0u && status == PGM_OK) {
+            bool iw;
+            need_window(y, x);
+            code_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)code_of(y, x, iw));
+        }
+        uint32_t guard = 0;
+        while ((x | y) != 0u && status == PGM_OK) {
+            if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
+            ++st_iter;
+            if (state == State_m) {
+                // ---- a diagonal run: lane k looks at cell (y - 1 - k, x - 1 - k) ----
+                if (y == 0u || x == 0u) { status = PGM_ERR_BACKTRACK; break; }
+                need_window(y - 1u, x - 1u);
+                const uint32_t kmax = min(min(y, x), 64u);            // cells that exist on this diagonal (lanes >= kmax: none)
+                const bool exists = (uint32_t)lane < kmax;
+                const uint32_t yy = exists ? y - 1u - (uint32_t)lane : 0u, xx = exists ? x - 1u - (uint32_t)lane : 0u;
+                bool iw;
+                const uint32_t c = code_of(yy, xx, iw);
+                // the walk stops in front of: a cell outside the window, START, a cell it enters in a gap state
+                const bool stop = !exists || !iw || (yy | xx) == 0u || (c & 8u) == 0u;
+                const unsigned long long sm = __builtin_amdgcn_ballot_w64(stop);
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)sm) - 1);   // (lane 63 < kmax <= 64 implies some lane stops only if ...: see below)
+                const uint32_t nrun = sm == 0ull ? 64u : p;           // cells entered in state M
+                flush(nrun + 1u);
+                if ((uint32_t)lane < nrun) { mb1[len - flushed + (uint32_t)lane] = yy; mb2[len - flushed + (uint32_t)lane] = xx; }
+                len += nrun;
+                if (nrun != 0u) {
+                    y -= nrun; x -= nrun;
+                    code_cur = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)(nrun - 1u));
+                }
+                if (sm == 0ull) continue;                              // 64 cells in state M: the run goes on
+                // lane p's cell ends the run: outside the window (next iteration stages it), START, or entered in a gap state
+                const uint32_t py = (uint32_t)__builtin_amdgcn_readlane((int)yy, (int)p), px = (uint32_t)__builtin_amdgcn_readlane((int)xx, (int)p);
+                const bool p_exists = p < kmax, p_in = __builtin_amdgcn_readlane((int)iw, (int)p) != 0;
+                if (!p_exists) { status = PGM_ERR_BACKTRACK; break; }  // the diagonal left the matrix without reaching START (cannot happen)
+                if (!p_in) continue;
+                y = py; x = px;
+                if ((y | x) == 0u) break;
+                code_cur = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)p);
+                state = state_of(code_cur);
+                push(state == State_x ? 0xFFFFFFFFu : y, state == State_y ? 0xFFFFFFFFu : x);
+                continue;
+            }
+            // ---- a gap state: one cell at a time ----
+            uint32_t ny = y, nx = x;
+            bool resolve;
+            if (state == State_y) {
+                if (y == 0u) { status = PGM_ERR_BACKTRACK; break; }
+                ny = y - 1; resolve = (code_cur & 1u) != 0u;
+            } else {
+                if (x == 0u) { status = PGM_ERR_BACKTRACK; break; }
+                nx = x - 1; resolve = (code_cur & 2u) != 0u;
+            }
+            uint32_t code_n = 0u;
+            if ((ny | nx) != 0u) {
+                bool iw;
+                need_window(ny, nx);
+                code_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)code_of(ny, nx, iw));
+                if (resolve) state = state_of(code_n);
+            }
+            y = ny; x = nx; code_cur = code_n;
+            if ((x | y) != 0u) push(state == State_x ? 0xFFFFFFFFu : y, state == State_y ? 0xFFFFFFFFu : x);
+        }
+        push(0u, 0u);
+        flush(MB + 1u);
+        if (len > n1 + n2) { status = PGM_ERR_BACKTRACK; len = n1 + n2; }
+        if (lane == 0) {
+            J.result->score = Wend;
+            J.result->n_tr_indels = 0;
+            J.result->len = len;
+            J.result->status = status;
+            *len_lds = len;
+            if (stat) {   // {ticks since the band end of wavefront 0 until the walk began << 40 | window ticks << 20 | walk ticks, windows << 32 | misses << 16 | iterations}
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                stat[0] = (((stat[1] - stat[-2]) & 0xfffffull) << 40) | ((st_win & 0xfffffull) << 20) | ((now - stat[1]) & 0xfffffull);
+                stat[1] = (st_nwin << 32) | (st_miss << 16) | st_iter;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    pgm_traceback_publish(J, *len_lds, tid, nthreads);
+}
+
 // Helper wavefronts of a MODE 2 sweep (PgmJob::mode2): wavefronts 1-7 of the worker.  The sweeping wavefront keeps the terms
 // it can evaluate from its own register windows (chain M, X, Y; X from columns x-2, x-3, Y from row y-2, the M pairs
 // (y-1, x-2) and (y-2, x-1)).  Every other term of step t reads the history no later than step t - 3 (all but one no
@@ -1897,7 +2328,8 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
     // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
     __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
     __shared__ int item_lds, tb_go;
-    __shared__ __attribute__((aligned(16))) int fsync[12];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built
+    __shared__ uint32_t tb_len;
+    __shared__ __attribute__((aligned(16))) int fsync[16];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built; lean item: [0..7] columns produced, [8..15] columns consumed by wavefront w
     static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
@@ -1909,7 +2341,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
-            for (int k = 0; k < 12; ++k) fsync[k] = 0;
+            for (int k = 0; k < 16; ++k) fsync[k] = 0;
         }
         __syncthreads();
         const int it = item_lds;
@@ -1923,9 +2355,17 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
         if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
         const PgmJob &J = jobs[item.job];
         const uint32_t b = item.band + (uint32_t)role;
-        const bool last_band = (item.band + item.count == J.nb);
+        const bool last_band = J.lean != 0 || (item.band + item.count == J.nb);   // (a lean item is the whole job)
         const unsigned long long clk0 = (DBG && trace) ? __builtin_readcyclecounter() : 0ull;
-        if ((uint32_t)role < item.count) {
+        if (J.lean) {
+#ifdef PGM_TOOLS   // (the release library sweeps lean jobs with R = 2 rows per lane; the tools build can try 1 and 4)
+            if (J.rshift == 2u) { if (J.keep_cells) pgm_sweep_chain<4, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); else pgm_sweep_chain<4, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); }
+            else if (J.rshift == 0u) { if (J.keep_cells) pgm_sweep_chain<1, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); else pgm_sweep_chain<1, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); }
+            else
+#endif
+            if (J.keep_cells) pgm_sweep_chain<2, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit);
+            else pgm_sweep_chain<2, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit);
+        } else if ((uint32_t)role < item.count) {
             unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helpers
             const bool stall = item.job == stall_job && b == stall_band;
             uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
@@ -1966,7 +2406,15 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             __syncthreads();
             if (tb_go != 0 && !NOTRACEBACK) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
-                pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+                if (trace && threadIdx.x == 0) trace[6 * it + 5] = __builtin_amdgcn_s_memrealtime();   // (the lean walker's statistics are relative to this)
+                if (J.lean) {
+#ifdef PGM_TOOLS
+                    if (J.rshift == 2u) pgm_traceback_chain<4>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+                    else if (J.rshift == 0u) pgm_traceback_chain<1>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+                    else
+#endif
+                    pgm_traceback_chain<2>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+                } else pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
             }
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         }

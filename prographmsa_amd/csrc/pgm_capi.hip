@@ -29,6 +29,13 @@
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &m) { g_err = m; return code; }
+// Experiment switches of tools/ (timeline, strip-down variants, work-list parameters) exist only in the tools build of the
+// library (make tools: -DPGM_TOOLS, lib/libpgm_hip_tools.so); the release library reads none of them.
+#ifdef PGM_TOOLS
+static const char *tools_env(const char *k) { return getenv(k); }
+#else
+static const char *tools_env(const char *) { return nullptr; }
+#endif
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \
@@ -394,10 +401,11 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
 
 // Device-only regions of one job (offsets inside the batch's work / cell / result / score buffers) and its slice of the
 // progress counters (pass 1 of pgm_align_batch_create).
-struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog; };
+struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog, codes, endcell; };
 struct BatchLayout { DevLayout W, C, O, SL; size_t sync_ints = 4; };   // sync: [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
-static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, JobOff &o) {
-    const uint32_t dp = dim <= 20 ? 20 : 64, nb = (n1 - 1 + PGM_ROWS - 1) / PGM_ROWS, tsteps = (n2 - 1) + 63;
+static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, uint32_t rshift, bool lean, bool keep, JobOff &o) {
+    const uint32_t R = 1u << rshift, rows = PGM_ROWS * R;
+    const uint32_t dp = dim <= 20 ? 20 : 64, nb = (n1 - 1 + rows - 1) / rows, tsteps = (n2 - 1) + 63;
     const uint32_t nblk = (tsteps + PGM_BLOCK - 1) / PGM_BLOCK, maxn = std::max(n1, n2);
     o.g1f = L.W.take(sizeof(float) * (size_t)dp * n1);
     o.a1 = L.W.take(sizeof(float) * n1);
@@ -410,11 +418,27 @@ static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, J
     o.ms = L.W.take(4 * (size_t)maxn);
     o.mp = L.W.take(4 * (size_t)maxn);
     o.res = L.O.take(sizeof(PgmJob::Result), 16);
-    o.cells = L.C.take(sizeof(float4) * (size_t)nb * tsteps * 64u, 1024);
-    o.S = L.SL.take(sizeof(float) * (size_t)nb * nblk * 64u * PGM_BLOCK, 1024);
+    o.cells = L.C.take(keep ? sizeof(float4) * (size_t)nb * tsteps * 64u * R : 16, 1024);   // (a lean job without the test hook: codes only)
+    o.codes = L.W.take(lean ? 4 * (size_t)nb * nblk * 64u * R : 16);   // one word per lane, row and block of eight steps
+    o.endcell = L.W.take(16, 16);
+    o.S = L.SL.take(sizeof(float) * (size_t)nb * nblk * 64u * PGM_BLOCK * R, 1024);
     o.prog = L.sync_ints;
     L.sync_ints += (nb + 3) / 4 * 4;
 }
+// A plain chain 0 -> 1 -> ... -> n-1 with finite edge costs and no repeat edges (a sequence graph).  Decided before the layout
+// pass because jobs of two such graphs get the lean sweep's storage (R rows per lane, code bytes, matrices only on request);
+// anything else — also a chain with a missing or infinite edge — takes the general path.
+static bool graph_is_chain(const pgm_graph *g) {
+    if (g->r_rowptr && g->r_rowptr[g->n] != 0) return false;
+    if (g->e_rowptr[0] != 0 || g->e_rowptr[1] != 0) return false;
+    for (uint32_t v = 1; v < g->n; ++v) {   // exactly the edge v-1 -> v, at finite cost (stored value 0 means +inf, Graph.h:223-231)
+        const int32_t eb = g->e_rowptr[v], ee = g->e_rowptr[v + 1];
+        if (eb < 0 || ee - eb != 1 || g->e_col[eb] != v - 1 || g->e_val[eb] == 0.0f) return false;
+    }
+    return true;
+}
+#define PGM_LEAN_RSHIFT 1   /* rows per lane of the lean sweep: R = 1 << PGM_LEAN_RSHIFT */
+
 // upper bound of the flattened input of one graph side with n nodes and E edges (regular + repeat)
 static size_t side_bound_bytes(size_t n, size_t dim, size_t E) {
     E = std::max<size_t>(E, 1);
@@ -527,6 +551,11 @@ extern "C" {
 
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_batch **out) {
+    return pgm_align_batch_create_ex(ctx, njobs, g1, g2, model, scores, 0u, out);
+}
+
+int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                              const pgm_model *const *model, const pgm_scores *scores, uint32_t flags, pgm_align_batch **out) {
     if (!ctx || !out || (njobs && (!g1 || !g2 || !model || !scores))) return fail(PGM_ERR_INVALID, "null argument");
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
@@ -557,20 +586,26 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         memset(&J, 0, sizeof J);
         J.n1 = a->n; J.n2 = c->n; J.dim = a->dim;
         J.dp = a->dim <= 20 ? 20 : 64;
-        J.nb = (a->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
         J.ncol = c->n - 1;
         J.tsteps = J.ncol + 63;
+        // chain-only jobs: the lean sweep, R rows per lane (the band's buffer descriptor must stay below 1 GiB: see pgm_sweep_chain)
+        uint32_t lean_rshift = PGM_LEAN_RSHIFT;
+        if (const char *v = tools_env("PGM_LEAN_RSHIFT")) lean_rshift = (uint32_t)std::min(2, std::max(0, atoi(v)));   // (tools build: R = 1, 2, 4)
+        J.lean = (!tools_env("PGM_NO_LEAN") && graph_is_chain(a) && graph_is_chain(c) && ((uint64_t)J.tsteps * 1024u << lean_rshift) < (1ull << 30)) ? 1u : 0u;
+        J.rshift = J.lean ? lean_rshift : 0u;
+        J.nb = (a->n - 1 + (PGM_ROWS << J.rshift) - 1) / (PGM_ROWS << J.rshift);
         J.nblk = (J.tsteps + PGM_BLOCK - 1) / PGM_BLOCK;
         b->maxnblk = std::max(b->maxnblk, J.nblk);
         J.maxn = std::max(a->n, c->n);
         b->maxn = std::max(b->maxn, J.maxn);
         J.sc = scores[i];
         b->maxdim = std::max(b->maxdim, a->dim);
-        b->maxnb = std::max(b->maxnb, J.nb);
+        b->maxnb = std::max(b->maxnb, J.nb << J.rshift);   // (bands of the emission kernel: R virtual bands per band)
         b->cells += (uint64_t)(a->n - 2) * (c->n - 2);
         Off &o = off[i];
         in_base[i + 1] = in_base[i] + side_bound(a) + side_bound(c) + model_bound_bytes(a->dim);
-        layout_job(L, J.n1, J.n2, J.dim, o);
+        J.keep_cells = (!J.lean || (flags & PGM_BATCH_KEEP_MATRICES)) ? 1u : 0u;
+        layout_job(L, J.n1, J.n2, J.dim, J.rshift, J.lean != 0, J.keep_cells != 0, o);
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
     }
     // The device buffers and the pinned result block are allocated (or taken from the context's cache) on a thread of their own
@@ -650,6 +685,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 Off &o = off[i];
                 if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); return; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
+                if (J.lean && J.has_extras) { bad.store((int)i); return; }   // (graph_is_chain and flatten_side disagree: cannot happen)
                 // LDS of one sweeping wavefront: W / Y history of hD steps x (64 lanes + 16 virtual lanes), X history of hDX
                 // steps x 64 lanes, 128 column summaries.  A pair (y - dy, x - dx) is read dy + dx steps back and the virtual
                 // lanes are written a block ahead: hD >= maxd1 + maxd2 + 8, hDX >= maxd2 + 1 (powers of two).
@@ -687,6 +723,7 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
                 if (J.long1 | J.long2) J.slot_bytes += 3u * 32u * 64u * 4u;   // W of the last 32 columns of every remote row's walk (one ring per row helper)
                 J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.nslots = J.mode2 ? 1u : std::max(1u, std::min((uint32_t)PGM_WAVES, (uint32_t)PGM_POOL / J.slot_bytes));
+                if (J.lean) J.nslots = PGM_WAVES;
                 if (job_stats) {   // tools: how the nodes of this job are served
                     uint32_t gen[2] = {0, 0}, lng = 0;
                     for (int side = 0; side < 2; ++side) {
@@ -769,6 +806,8 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         J.hmap1 = (uint32_t *)(h_out_dev + o.map1); J.hmap2 = (uint32_t *)(h_out_dev + o.map2);
         J.hresult = (PgmJob::Result *)(h_out_dev + o.res);
         J.cells = (float4 *)(b->d_cells + o.cells);
+        J.codes = (uint32_t *)(w + o.codes);
+        J.endcell = (float4 *)(w + o.endcell);
         J.S = (float *)(b->d_S + o.S);
         J.prog = b->d_sync + o.prog;
     }
@@ -794,8 +833,9 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
         std::vector<std::vector<Item>> per_job(njobs);
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
-        auto envd = [](const char *k, double d) { const char *v = getenv(k); return v ? atof(v) : d; };   // experiments only
+        auto envd = [](const char *k, double d) { const char *v = tools_env(k); return v ? atof(v) : d; };   // tools build only
         const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
+        const double tau_l = envd("PGM_SIM_TAU_L", 0.15);   // lean sweep: us per step of R rows per lane
         size_t total = 0;
         double rmax = 1.0;
         for (uint32_t i = 0; i < njobs; ++i) {
@@ -803,6 +843,17 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
             const double tau = J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c);     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             const uint32_t group = J.nslots;                     // bands per item, one per wavefront of the worker
+            if (J.lean) {   // one item: the worker's wavefronts cycle over the bands (hand-off through LDS: 72 steps behind each other)
+                const double rounds = std::ceil((double)J.nb / PGM_WAVES), first = std::min<double>(J.nb, PGM_WAVES);
+                Item it;
+                it.rem = it.dur = tau_l * (rounds * J.tsteps + (first - 1.0) * 72.0) + 0.15 * (double)(J.n1 + J.n2);
+                it.gap = 0.0;
+                it.job = i; it.band = 0; it.count = (uint32_t)first;
+                per_job[i].push_back(it);
+                rmax = std::max(rmax, it.rem);
+                total += 1;
+                continue;
+            }
             for (uint32_t band = 0; band < J.nb; band += group) {
                 const uint32_t cnt = std::min(group, J.nb - band);
                 const bool last = band + cnt == J.nb;
@@ -1015,8 +1066,11 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const PgmJob &J = b->jobs[job];
     const size_t N = (size_t)J.n1 * J.n2;
+    if ((M || X || Y || W) && !J.keep_cells)
+        return fail(PGM_ERR_INVALID, "the DP matrices of a chain-only job are only kept for a batch created with PGM_BATCH_KEEP_MATRICES");
     if (M || X || Y || W) {
-        const size_t ncell = (size_t)J.nb * J.tsteps * 64u;
+        const uint32_t sh = J.rshift, R = 1u << sh;
+        const size_t ncell = (size_t)J.nb * J.tsteps * 64u * R;
         std::vector<float4> cells(ncell);
         HIPCHK(hipMemcpy(cells.data(), J.cells, ncell * sizeof(float4), hipMemcpyDeviceToHost));
         float *dst[4] = {M, X, Y, W};
@@ -1024,8 +1078,8 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
             if (dst[k]) std::fill(dst[k], dst[k] + N, -INFINITY);
         for (uint32_t y = 0; y + 1 < J.n1; ++y)
             for (uint32_t x = 0; x < J.ncol; ++x) {
-                const uint32_t bb = y / PGM_ROWS, l = PGM_HALO + (y - bb * PGM_ROWS);
-                const float4 c = cells[((size_t)bb * J.tsteps + (x + l)) * 64u + l];  // {M, X, W, Y}
+                const uint32_t bb = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & (R - 1u);
+                const float4 c = cells[((((size_t)bb * J.tsteps + (x + l)) << sh) | r) * 64u + l];  // {M, X, W, Y}
                 const size_t i = (size_t)y + (size_t)J.n1 * x;
                 if (M) M[i] = c.x;
                 if (X) X[i] = c.y;
@@ -1035,14 +1089,15 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
     }
     if (S) {
         // the emission scores exactly as the fill kernel consumes them (PgmJob::S, written by pgm_emission_skew_kernel), de-skewed
-        const size_t ns = (size_t)J.nb * J.nblk * 64u * PGM_BLOCK;
+        const uint32_t sh = J.rshift, R = 1u << sh;
+        const size_t ns = (size_t)J.nb * J.nblk * 64u * PGM_BLOCK * R;
         std::vector<float> sk(ns);
         HIPCHK(hipMemcpy(sk.data(), J.S, ns * sizeof(float), hipMemcpyDeviceToHost));
         std::fill(S, S + N, 0.0f);
         for (uint32_t y = 0; y + 1 < J.n1; ++y)
             for (uint32_t x = 0; x < J.ncol; ++x) {
-                const uint32_t bb = y / PGM_ROWS, l = PGM_HALO + (y - bb * PGM_ROWS), t = x + l;
-                S[(size_t)y + (size_t)J.n1 * x] = sk[(((size_t)bb * J.nblk + t / PGM_BLOCK) * 64u + l) * PGM_BLOCK + t % PGM_BLOCK];
+                const uint32_t bb = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & (R - 1u), t = x + l;
+                S[(size_t)y + (size_t)J.n1 * x] = sk[(((((size_t)bb * J.nblk + t / PGM_BLOCK) << sh) | r) * 64u + l) * PGM_BLOCK + t % PGM_BLOCK];
             }
     }
     return PGM_OK;

@@ -67,7 +67,8 @@ struct PgmNode2 {
 // the wavefronts produce it: rows are cut into bands of 64; a band is swept by one wavefront whose
 // lane l owns row y = 64 b + l, with lane l one column behind lane l-1, so "step" t of band b holds
 // the cells (y = 64 b + l, x = t - l) at cells[((b * tsteps) + t) * 64 + l]  — every wave-level
-// store is one contiguous 1 KB run.
+// store is one contiguous 1 KB run.  With R = 1 << rshift rows per lane (lean jobs) a band is 64 R rows, lane l owns the
+// rows 64 R b + R l + r (r < R) and step t holds R such runs: cells[(((b * tsteps) + t) * R + r) * 64 + l].
 // Rows 0..n1-2 and columns 0..n2-2 are stored (the END row/column are never written by the reference
 // either); row 0 / column 0 are the border initialisation of GraphAlign.h:212-234.
 // Predecessor record of one node for the traceback's tile staging: the first PGM_TB_PK entries of the node's list in
@@ -85,7 +86,7 @@ struct PgmTbNode {
 struct PgmJob {
     uint32_t n1, n2;       // node counts incl. START/END
     uint32_t dim, dp;      // alphabet size and padded size (multiple of 4)
-    uint32_t nb;           // number of row bands = ceil((n1-1)/64)
+    uint32_t nb;           // number of row bands = ceil((n1-1)/(64 R))
     uint32_t ncol;         // stored columns = n2-1
     uint32_t tsteps;       // steps per band = ncol + 63
     uint32_t maxn;         // max(n1,n2)
@@ -97,6 +98,10 @@ struct PgmJob {
     uint32_t hD, hDX;      // depth (steps, power of two) of the W / Y history and of the X history of a sweeping wavefront
     uint32_t slot_bytes;   // LDS bytes one sweeping wavefront needs for this job (history + column rings)
     uint32_t nslots;       // bands of this job one worker sweeps at a time = min(8, PGM_POOL / slot_bytes)
+    uint32_t rshift;       // log2 of the rows a lane of a sweeping wavefront owns (R = 1 << rshift consecutive rows: a band is 64 R rows);
+                           // cell and score storage are laid out per (band, step, r, lane), see `cells` / `S` below
+    uint32_t lean;         // chain-only job (has_extras == 0): swept by pgm_sweep_chain — all bands of the job by ONE worker whose
+                           // wavefronts hand the band's last row over through LDS rings (no hand-off through memory)
     uint32_t long1, long2; // mode2 only: graph 1 has REMOTE row entries / graph 2 has LONG column entries (served from the cell
                            // storage by the far helpers: farther than PGM_DCAP, or reaching above the band's virtual lanes)
     pgm_scores sc;
@@ -130,11 +135,18 @@ struct PgmJob {
 
     // emission scores produced by the emission kernel, in the order the fill kernel consumes them:
     // S[((b * nblk + (t >> 3)) * 64 + lane) * 8 + (t & 7)] = S(y, x) of the cell lane `lane` of band b owns at step t
+    // (R rows per lane: S[(((b * nblk + (t >> 3)) * R + r) * 64 + lane) * 8 + (t & 7)])
     float *S;
     uint32_t nblk;         // ceil(tsteps / 8)
 
+    // lean jobs: the traceback's decisions, four bits per cell (see pgm_sweep_chain), [nb][nblk][R][64] words of eight
+    // steps; the END node's predecessor cell (n1-2, n2-2) {M, X, W, Y}; whether the four matrices are written to `cells` at all
+    uint32_t *codes;
+    float4 *endcell;
+    uint32_t keep_cells;
+
     // DP storage
-    float4 *cells;         // [nb][tsteps][64]
+    float4 *cells;         // [nb][tsteps][R][64]
     int *prog;             // [nb] steps of band b that are complete and visible device-wide (zeroed before every launch)
 
     // traceback output + scratch

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import (PGM_GAP, check, lib, pgm_align_out, pgm_graph, pgm_model, pgm_scores)
+from . import (PGM_BATCH_KEEP_MATRICES, PGM_GAP, check, lib, pgm_align_out, pgm_graph, pgm_model, pgm_scores)
 
 MAGIC = 0x4A4D4750
 
@@ -135,12 +135,13 @@ def align_graphs_batch(ctx, jobs):
 class Batch:
     """Staged form: create (upload) / run / fetch, inputs stay resident in HBM between runs."""
 
-    def __init__(self, ctx, jobs):
+    def __init__(self, ctx, jobs, keep_matrices=False):
+        """keep_matrices: PGM_BATCH_KEEP_MATRICES (every job's M, X, Y, W stay readable through read_matrices: test hook)."""
         self.ctx = ctx
         self.cj = CJobs(jobs)
         self.handle = C.c_void_p()
-        check(lib.pgm_align_batch_create(ctx.handle, self.cj.n, self.cj.g1, self.cj.g2, self.cj.m, self.cj.sc,
-                                         C.byref(self.handle)), "pgm_align_batch_create")
+        check(lib.pgm_align_batch_create_ex(ctx.handle, self.cj.n, self.cj.g1, self.cj.g2, self.cj.m, self.cj.sc,
+                                            PGM_BATCH_KEEP_MATRICES if keep_matrices else 0, C.byref(self.handle)), "pgm_align_batch_create_ex")
 
     @property
     def cells(self):
@@ -187,7 +188,7 @@ class Batch:
 # -------------------------------------------------------------------------------------------------
 # Synthetic jobs for parity tests: random DAGs with skip edges, unreachable-cost edges and repeat edges.
 def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, drop_chain_frac=0.03, skip_span=12, skip_max=3,
-                 repeat_span=20):
+                 repeat_span=20, chain_cost_frac=0.0):
     sites = np.zeros((n, dim))
     for i in range(1, n - 1):
         if rng.random() < onehot_frac:
@@ -201,7 +202,7 @@ def random_graph(rng, n, dim, skip_frac=0.15, repeat_frac=0.0, onehot_frac=0.5, 
         preds = {}
         if v > 0:
             if rng.random() >= drop_chain_frac or v == 1:
-                preds[v - 1] = 0.0
+                preds[v - 1] = 0.0 if rng.random() >= chain_cost_frac else float(rng.choice([0.80369, 1.60738, 2.5]))
             if v > 1 and rng.random() < skip_frac:
                 for _ in range(int(rng.integers(1, skip_max + 1))):
                     p = int(rng.integers(max(0, v - skip_span), v))

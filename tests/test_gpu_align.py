@@ -28,6 +28,7 @@ def _cmp_job(batch, idx, job, res):
 FAMILIES = [
     dict(skip_frac=0.0, drop_chain_frac=0.0),                 # pure chains (leaf vs leaf)
     dict(skip_frac=0.0, drop_chain_frac=0.0, onehot_frac=1.0),   # ... with one-hot rows throughout: the emission kernel's score table per (symbol, column)
+    dict(skip_frac=0.0, drop_chain_frac=0.0, chain_cost_frac=0.2),   # chain-only with costs on some chain edges (lean sweep, R rows per lane)
     dict(skip_frac=0.1, onehot_frac=0.97),                    # almost one-hot: workgroups with and without other rows
     dict(skip_frac=0.2),                                      # merged-graph like skip edges: near window + LDS history
     dict(skip_frac=0.3, repeat_frac=0.05),                    # + tandem-repeat edges
@@ -47,16 +48,31 @@ FAMILIES = [
 def test_random_jobs_bit_exact(ctx, kw, dim):
     from prographmsa_amd import jobs as J
     sizes = [(2, 2), (3, 2), (2, 5), (3, 3), (7, 4), (40, 33), (64, 64), (65, 66), (66, 65), (130, 97), (200, 310), (517, 129)]
+    if kw.get("skip_frac", 1) == 0.0:   # chain-only: more than eight bands of 128 / 256 rows (the worker's wavefronts take a second band), ring wrap-around
+        sizes = sizes + [(129, 130), (257, 70), (1100, 700), (2500, 90), (90, 2300)]
     if dim == 61:   # the 61-state alphabet (codons): fewer sizes, same families incl. skip and repeat edges
         sizes = [(3, 2), (7, 4), (65, 66), (130, 97), (200, 310)]
     if kw.get("skip_span", 0) >= 60 or kw.get("skip_max", 0) >= 10:   # several bands with remote rows and long columns in flight
         sizes = sizes + [(700, 650)]
     js = [J.random_job(1000 + i, n1, n2, dim=dim, **kw) for i, (n1, n2) in enumerate(sizes)]
-    b = J.Batch(ctx, js)
+    b = J.Batch(ctx, js, keep_matrices=True)
     b.run()
     res = b.fetch()
     for i, j in enumerate(js):
         _cmp_job(b, i, j, res[i])
+    b.close()
+    # the product's form of the batch (no test hook: chain-only jobs keep decision bytes instead of the matrices): same results
+    b = J.Batch(ctx, js)
+    b.run()
+    res2 = b.fetch()
+    for r, r2 in zip(res, res2):
+        assert r["status"] == r2["status"] == 0 and r["n_tr_indels"] == r2["n_tr_indels"]
+        assert np.float32(r["score"]).view(np.uint32) == np.float32(r2["score"]).view(np.uint32)
+        assert np.array_equal(r["map1"], r2["map1"]) and np.array_equal(r["map2"], r2["map2"])
+    if kw.get("skip_frac", 1) == 0.0 and len(js) > 12:
+        import prographmsa_amd as pg
+        with pytest.raises(pg.PgmError):
+            b.read_matrices(12)   # not kept
     b.close()
 
 
@@ -67,7 +83,7 @@ def test_large_heavy_tailed_jobs_bit_exact(ctx):
     js = [J.random_job(77, 2300, 2200, skip_frac=0.3, skip_span=150, skip_max=5),
           J.random_job(78, 1500, 2600, skip_frac=0.5, skip_span=27, skip_max=14),
           J.random_job(79, 2600, 1400, skip_frac=0.25, skip_span=90, skip_max=6, repeat_frac=0.03, repeat_span=120)]
-    b = J.Batch(ctx, js)
+    b = J.Batch(ctx, js, keep_matrices=True)
     b.run()
     res = b.fetch()
     for i, j in enumerate(js):
@@ -80,7 +96,7 @@ def test_relaunch_and_fetch(ctx):
     out by fetch while the kernel is still running (status word last); every fetch returns the same results."""
     from prographmsa_amd import jobs as J
     js = [J.random_job(300 + i, 260 + 37 * i, 300 - 11 * i, skip_frac=0.2) for i in range(12)]
-    b = J.Batch(ctx, js)
+    b = J.Batch(ctx, js, keep_matrices=True)
     b.run(); b.run()
     r1 = b.fetch()
     b.run()

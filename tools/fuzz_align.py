@@ -27,7 +27,7 @@ while time.time() < t_end:
     big = rng.random() < 0.15
     sizes = [(int(rng.integers(2, 2600 if big else 700)), int(rng.integers(2, 2600 if big else 700))) for _ in range(3 if big else int(rng.integers(1, 24)))]
     js = [J.random_job(int(rng.integers(1 << 30)), n1, n2, dim=dim, **kw) for n1, n2 in sizes]
-    b = J.Batch(ctx, js)
+    b = J.Batch(ctx, js, keep_matrices=True)
     b.run()
     res = b.fetch()
     want = [k == 0 for k in range(len(js))]          # matrices of the first job of every batch

@@ -21,7 +21,7 @@ cases = [
 ]
 for name, specs in cases:
     js = [J.random_job(500 + i, sp["n1"], sp["n2"], **{k: v for k, v in sp.items() if k not in ("n1", "n2")}) for i, sp in enumerate(specs)]
-    b = J.Batch(ctx, js)
+    b = J.Batch(ctx, js, keep_matrices=True)
     b.run()
     res = b.fetch()
     bad = 0

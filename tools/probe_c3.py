@@ -16,7 +16,7 @@ dump = os.path.join(tmp, "jobs.bin")
 subprocess.run([oracle_lib.PGMSA_ORACLE, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree"), "--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
 jobs = J.load_jobs(dump)
 ctx = pg.Context(0)
-b = J.Batch(ctx, jobs)
+b = J.Batch(ctx, jobs, keep_matrices=True)
 for rep in range(3):
     b.run()
     res = b.fetch()

@@ -18,7 +18,7 @@ if which == "chain":
 elif which == "merged":
     jobs = jobs[128:]
 ctx = pg.Context(0)
-b = J.Batch(ctx, jobs)
+b = J.Batch(ctx, jobs, keep_matrices=True)
 b.run()
 res = b.fetch()
 bad = [i for i, (j, r) in enumerate(zip(jobs, res)) if r["status"] != 0]

@@ -16,6 +16,8 @@ fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam()))
 dump = os.path.join(tmp, "jobs.bin")
 subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
 jobs = J.load_jobs(dump)
+if os.environ.get("PROBE_LEAF"):   # the chain-only jobs (leaf level) alone
+    jobs = sorted(jobs, key=lambda j: j.cells)[:int(os.environ["PROBE_LEAF"])]
 os.environ["PGM_FILL_TRACE"] = trace
 for kv in os.environ.get("PROBE_ENV", "").split(","):   # experiment knobs that must not reach the product run above
     if "=" in kv:
@@ -46,6 +48,17 @@ late = np.argsort(-end)[:12]
 for i in late:
     j, bd = items[i]
     print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 63) // 64, start[i], bend[i], tend[i]))
+lean = np.array([j.g1.e_col.size == j.g1.n - 1 and j.g2.e_col.size == j.g2.n - 1 for j in jobs])
+li = [i for i in range(n) if tend[i] > 0 and lean[items[i, 0]]]
+if li:   # lean jobs: the chain walker's counters
+    w, v = raw[li, 5], raw[li, 4]
+    wait_us = ((v >> np.uint64(40)) & np.uint64(0xfffff)).astype(float) / 100.0
+    win_us = ((v >> np.uint64(20)) & np.uint64(0xfffff)).astype(float) / 100.0
+    walk_us = (v & np.uint64(0xfffff)).astype(float) / 100.0
+    tot = tend[li] - bend[li]
+    print("lean jobs: %d; wavefront 0 sweeps %.0f us; then %.0f us until every band is done, walk %.0f us (of which window switches %.1f us: %.1f windows, %.1f not prefetched; %.1f loop iterations), publish %.0f us" % (
+        len(li), (bend[li] - start[li]).mean(), wait_us.mean(), walk_us.mean(), win_us.mean(), (w >> np.uint64(32)).astype(float).mean(),
+        ((w >> np.uint64(16)) & np.uint64(0xffff)).astype(float).mean(), (w & np.uint64(0xffff)).astype(float).mean(), (tot - wait_us - walk_us).mean()))
 tbi = np.where(tend > 0)[0]
 rel = (raw[tbi, 4] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
 stg = (raw[tbi, 4] >> np.uint64(32)).astype(np.float64) / 100.0   # of which: loads -> LDS (the rest is the link pass)
