@@ -124,6 +124,10 @@ uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
  * band walks that job's path), so ms_fill includes them and ms_traceback is ~0. */
 int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
                          float *ms_emission, float *ms_fill, float *ms_traceback);
+/* Test hook for the hand-off time-out path: in the following launches band `band` of job `job` never publishes its progress
+ * and a wavefront that waits for another gives up after `spin_limit` polls (0: the default); the band below then times out,
+ * raises the batch's abort flag and every unfinished job reports PGM_ERR_DEVICE.  job = 0xFFFFFFFF switches it off. */
+int pgm_align_batch_test_stall(pgm_align_batch *b, uint32_t job, uint32_t band, uint32_t spin_limit);
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
  * column-major, element (y,x) at y + x*n1).  Only rows < n1-1 and columns < n2-1 are
  * defined (the END row/column are never written by the reference's fill either).

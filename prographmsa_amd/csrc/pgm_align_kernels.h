@@ -139,10 +139,10 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
 
 // ---------------------------------------------------------------------------------------------
 // cell addressing (see PgmJob): cell = float4 {M, X, W, Y}
-// (R = 1 << J.rshift rows per lane: band b = y / (64 R), lane l = (y % (64 R)) / R, r = y % R)
+// (jobs of the fill kernel: one row per lane; the lean kernel keeps no cells unless asked to and never reads them back)
 __device__ __forceinline__ size_t pgm_cell_index(const PgmJob &J, uint32_t y, uint32_t x) {
-    const uint32_t sh = J.rshift, b = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & ((1u << sh) - 1u);
-    return ((((size_t)b * J.tsteps + (x + l)) << sh) | r) * 64u + l;
+    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS);
+    return ((size_t)b * J.tsteps + (x + l)) * 64u + l;
 }
 __device__ __forceinline__ float4 pgm_load_cell(const PgmJob &J, uint32_t y, uint32_t x) {
     return J.cells[pgm_cell_index(J, y, x)];
@@ -446,8 +446,8 @@ __device__ static void pgm_mark_alternative_path(const PgmJob &J, uint32_t start
 
 // S(y,x) as the emission kernel stored it (skewed order, see PgmJob::S): one load instead of recomputing the dot product
 __device__ __forceinline__ float pgm_emission_at(const PgmJob &J, uint32_t y, uint32_t x) {
-    const uint32_t sh = J.rshift, b = y >> (6u + sh), w = y & ((64u << sh) - 1u), l = w >> sh, r = w & ((1u << sh) - 1u), t = x + l;
-    return J.S[(((((size_t)b * J.nblk + (t / PGM_BLOCK)) << sh) | r) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
+    const uint32_t b = y / PGM_ROWS, l = PGM_HALO + (y - b * PGM_ROWS), t = x + l;
+    return J.S[(((size_t)b * J.nblk + (t / PGM_BLOCK)) * 64u + l) * PGM_BLOCK + (t % PGM_BLOCK)];
 }
 
 #ifndef PGM_POLL_PREFETCH
@@ -2328,8 +2328,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
     // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
     __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
     __shared__ int item_lds, tb_go;
-    __shared__ uint32_t tb_len;
-    __shared__ __attribute__((aligned(16))) int fsync[16];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built; lean item: [0..7] columns produced, [8..15] columns consumed by wavefront w
+    __shared__ __attribute__((aligned(16))) int fsync[12];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built
     static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
@@ -2341,7 +2340,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
-            for (int k = 0; k < 16; ++k) fsync[k] = 0;
+            for (int k = 0; k < 12; ++k) fsync[k] = 0;
         }
         __syncthreads();
         const int it = item_lds;
@@ -2355,17 +2354,9 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
         if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
         const PgmJob &J = jobs[item.job];
         const uint32_t b = item.band + (uint32_t)role;
-        const bool last_band = J.lean != 0 || (item.band + item.count == J.nb);   // (a lean item is the whole job)
+        const bool last_band = (item.band + item.count == J.nb);
         const unsigned long long clk0 = (DBG && trace) ? __builtin_readcyclecounter() : 0ull;
-        if (J.lean) {
-#ifdef PGM_TOOLS   // (the release library sweeps lean jobs with R = 2 rows per lane; the tools build can try 1 and 4)
-            if (J.rshift == 2u) { if (J.keep_cells) pgm_sweep_chain<4, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); else pgm_sweep_chain<4, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); }
-            else if (J.rshift == 0u) { if (J.keep_cells) pgm_sweep_chain<1, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); else pgm_sweep_chain<1, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit); }
-            else
-#endif
-            if (J.keep_cells) pgm_sweep_chain<2, true>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit);
-            else pgm_sweep_chain<2, false>(J, role, lane, L.pool, fsync, abort_flag, aborted, spin_limit);
-        } else if ((uint32_t)role < item.count) {
+        if ((uint32_t)role < item.count) {
             unsigned long long wait_ticks[2] = {0, 0};   // timeline only: waiting for band b-1, waiting for the helpers
             const bool stall = item.job == stall_job && b == stall_band;
             uint8_t *slot = L.pool + (size_t)role * J.slot_bytes;
@@ -2406,20 +2397,62 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             __syncthreads();
             if (tb_go != 0 && !NOTRACEBACK) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
-                if (trace && threadIdx.x == 0) trace[6 * it + 5] = __builtin_amdgcn_s_memrealtime();   // (the lean walker's statistics are relative to this)
-                if (J.lean) {
-#ifdef PGM_TOOLS
-                    if (J.rshift == 2u) pgm_traceback_chain<4>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
-                    else if (J.rshift == 0u) pgm_traceback_chain<1>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
-                    else
-#endif
-                    pgm_traceback_chain<2>(J, L.pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
-                } else pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+                pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
             }
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The lean jobs of a batch (PgmJob::lean) have a kernel of their own: they share nothing with the other jobs, and compiled
+// into pgm_fill_kernel their code changed the register allocation of that kernel's hot loops (the band sweeps and the helper
+// wavefronts ran 6-30 % slower).  Here it gets its own budget (one worker of eight wavefronts per CU, like the fill kernel).
+// Persistent workers take whole jobs (largest first) through an atomic ticket; a job's eight wavefronts sweep its bands
+// (pgm_sweep_chain), then wavefront 0 walks the decision bits (pgm_traceback_chain).  The host launches it on a second
+// stream beside pgm_fill_kernel, whose grid leaves the CUs for it free.
+#define PGM_LEAN_LDS (8 * PGM_LEAN_RING * 8 > 49152 ? 8 * PGM_LEAN_RING * 8 : 49152)
+template <int R>
+__global__ void __launch_bounds__(64 * PGM_WAVES, 2) pgm_lean_kernel(const PgmJob *__restrict__ jobs, const uint32_t *__restrict__ list, uint32_t nlist,
+                                                                  int *__restrict__ sync, unsigned long long *__restrict__ trace, uint32_t spin_limit) {
+    __shared__ __attribute__((aligned(16))) uint8_t pool[PGM_LEAN_LDS];   // rings of the sweep; windows and mapping block of the walk
+    __shared__ __attribute__((aligned(16))) int fsync[16];                // [0..7] columns produced, [8..15] columns consumed by wavefront w
+    __shared__ int item_lds, tb_go;
+    __shared__ uint32_t tb_len;
+    int *abort_flag = sync;        // [0] abort flag of the batch, [2] ticket counter of the lean list
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    bool aborted = false;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int it = -1;
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                it = __hip_atomic_fetch_add(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item_lds = (it >= 0 && (uint32_t)it < nlist) ? it : -1;
+            for (int k = 0; k < 16; ++k) fsync[k] = 0;
+        }
+        __syncthreads();
+        const int it = item_lds;
+        if (it < 0) break;
+        const PgmJob &J = jobs[list[it]];
+        if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
+        if (J.keep_cells) pgm_sweep_chain<R, true>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
+        else pgm_sweep_chain<R, false>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
+        if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+            tb_go = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (tb_go != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (trace && threadIdx.x == 0) trace[6 * it + 5] = __builtin_amdgcn_s_memrealtime();   // (the walker's statistics are relative to this)
+            pgm_traceback_chain<R>(J, pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+        }
+        if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
 
 #endif

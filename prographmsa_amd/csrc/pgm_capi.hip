@@ -46,6 +46,7 @@ static const char *tools_env(const char *) { return nullptr; }
 struct pgm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
     // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
     enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SMALL, C_SLOTS };   // C_HOST, C_HIN: pinned host memory; C_SMALL: the batch's counters, job descriptors, work list
@@ -131,6 +132,7 @@ struct DevLayout {  // sizes of device-only regions
     }
 };
 
+#define PGM_LEAN_RSHIFT_DEFAULT 1   /* rows per lane of the lean sweep: R = 1 << rshift (the release library: 2) */
 struct pgm_align_batch {
     uint32_t njobs = 0;
     uint64_t cells = 0;
@@ -150,8 +152,12 @@ struct pgm_align_batch {
     int *d_sync = nullptr;            // [0] abort flag, [1] band-list ticket, then the per-band progress counters of every job
     size_t sync_ints = 0, s_bytes = 0;
     PgmItem *d_items = nullptr;       // band list of the batch (fill work queue)
+    uint32_t *d_lean = nullptr;       // the lean jobs (pgm_lean_kernel's work queue), largest first
+    uint32_t nlean = 0, nlean_workers = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // stream -> stream2 after the emission kernel, stream2 -> stream after the lean kernel
     unsigned long long *d_trace = nullptr;   // PGM_FILL_TRACE=file: per-item timeline, written by fetch (tools only)
-    uint32_t nitems = 0;
+    uint32_t test_spin_limit = 0, test_stall_job = 0xFFFFFFFFu, test_stall_band = 0;   // pgm_align_batch_test_stall
+    uint32_t nitems = 0, lean_rshift = PGM_LEAN_RSHIFT_DEFAULT;
     uint32_t nworkers = 0, maxnblk = 0;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
@@ -185,6 +191,7 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     c->device = device;
     HIPCHK(hipGetDeviceProperties(&c->prop, device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -214,6 +221,7 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     for (int k = 0; k < 2; ++k) if (ctx->sc_ev[k]) (void)hipEventDestroy(ctx->sc_ev[k]);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
         if (ctx->cache_ptr[k]) slot_free(k, ctx->cache_ptr[k]);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -437,7 +445,7 @@ static bool graph_is_chain(const pgm_graph *g) {
     }
     return true;
 }
-#define PGM_LEAN_RSHIFT 1   /* rows per lane of the lean sweep: R = 1 << PGM_LEAN_RSHIFT */
+
 
 // upper bound of the flattened input of one graph side with n nodes and E edges (regular + repeat)
 static size_t side_bound_bytes(size_t n, size_t dim, size_t E) {
@@ -527,20 +535,33 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
     // One kernel does the DP fill of every band and, right after a job's last band, that job's traceback.
-    const char *dbg = getenv("PGM_FILL_DBG");   // 8: the fill alone, no traceback (tools)
+    const char *dbg = tools_env("PGM_FILL_DBG");   // 8: the fill alone, no traceback (tools build)
     const int dbgv = dbg ? atoi(dbg) : 0;
     // test knobs for the hand-off time-out path (tests/test_gpu_align.py): a shorter spin limit, and one band of one job
     // that never publishes its progress ("job:band"), so that the band below it times out and the batch aborts
-    uint32_t spin_limit = PGM_SPIN_LIMIT, stall_job = 0xFFFFFFFFu, stall_band = 0;
-    if (const char *v = getenv("PGM_TEST_SPIN_LIMIT")) spin_limit = (uint32_t)std::max(1, atoi(v));
-    if (const char *v = getenv("PGM_TEST_STALL")) { unsigned a = 0, c = 0; if (sscanf(v, "%u:%u", &a, &c) == 2) { stall_job = a; stall_band = c; } }
+    const uint32_t spin_limit = b->test_spin_limit ? b->test_spin_limit : PGM_SPIN_LIMIT, stall_job = b->test_stall_job, stall_band = b->test_stall_band;   // (pgm_align_batch_test_stall)
     // timing experiments only (results are garbage): 1 = the cell stores are dropped, 2 = the sweeping wavefront of a MODE 2 band
     // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
-    const uint32_t dbg_flags = getenv("PGM_TEST_NOSTORE") ? (uint32_t)atoi(getenv("PGM_TEST_NOSTORE")) : 0u;
-    if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    const uint32_t dbg_flags = tools_env("PGM_TEST_NOSTORE") ? (uint32_t)atoi(tools_env("PGM_TEST_NOSTORE")) : 0u;   // (tools build)
+    const bool fork = b->nlean != 0;
+    if (fork && ((e = hipEventRecord(b->ev_fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess)) return e;
+    if (b->nitems == 0) {}   // (a batch of lean jobs only)
+    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (fork) {
+        // the lean jobs' kernel, launched after the fill kernel (whose grid leaves nlean_workers CUs free)
+        unsigned long long *tr2 = b->d_trace ? b->d_trace + 22 * (size_t)b->nitems : nullptr;
+#ifdef PGM_TOOLS
+        if (b->lean_rshift == 2u) hipLaunchKernelGGL((pgm_lean_kernel<4>), dim3(b->nlean_workers), dim3(64 * PGM_WAVES), 0, ctx->stream2, b->d_jobs, b->d_lean, b->nlean, b->d_sync, tr2, spin_limit);
+        else if (b->lean_rshift == 0u) hipLaunchKernelGGL((pgm_lean_kernel<1>), dim3(b->nlean_workers), dim3(64 * PGM_WAVES), 0, ctx->stream2, b->d_jobs, b->d_lean, b->nlean, b->d_sync, tr2, spin_limit);
+        else
+#endif
+        hipLaunchKernelGGL((pgm_lean_kernel<2>), dim3(b->nlean_workers), dim3(64 * PGM_WAVES), 0, ctx->stream2, b->d_jobs, b->d_lean, b->nlean, b->d_sync, tr2, spin_limit);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(b->ev_join, ctx->stream2)) != hipSuccess || (e = hipStreamWaitEvent(s, b->ev_join, 0)) != hipSuccess) return e;
+    }
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
@@ -589,8 +610,9 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         J.ncol = c->n - 1;
         J.tsteps = J.ncol + 63;
         // chain-only jobs: the lean sweep, R rows per lane (the band's buffer descriptor must stay below 1 GiB: see pgm_sweep_chain)
-        uint32_t lean_rshift = PGM_LEAN_RSHIFT;
+        uint32_t lean_rshift = PGM_LEAN_RSHIFT_DEFAULT;
         if (const char *v = tools_env("PGM_LEAN_RSHIFT")) lean_rshift = (uint32_t)std::min(2, std::max(0, atoi(v)));   // (tools build: R = 1, 2, 4)
+        b->lean_rshift = lean_rshift;
         J.lean = (!tools_env("PGM_NO_LEAN") && graph_is_chain(a) && graph_is_chain(c) && ((uint64_t)J.tsteps * 1024u << lean_rshift) < (1ull << 30)) ? 1u : 0u;
         J.rshift = J.lean ? lean_rshift : 0u;
         J.nb = (a->n - 1 + (PGM_ROWS << J.rshift) - 1) / (PGM_ROWS << J.rshift);
@@ -628,7 +650,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     for (uint32_t i = 0; i < njobs; ++i) total_bands += b->jobs[i].nb;
     DevLayout SM;
     const size_t small_sync = SM.take(sync_ints * sizeof(int)), small_jobs = SM.take(sizeof(PgmJob) * std::max(1u, njobs)),
-                 small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands));
+                 small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)),
+                 small_lean = SM.take(4 * (size_t)std::max(1u, njobs));
     const size_t small_bytes = SM.bytes;
     std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
     std::atomic<int> upload_err((int)hipSuccess);
@@ -646,6 +669,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
             b->d_jobs = (PgmJob *)(b->d_small + small_jobs);
             b->d_order = (uint32_t *)(b->d_small + small_order);
             b->d_items = (PgmItem *)(b->d_small + small_items);
+            b->d_lean = (uint32_t *)(b->d_small + small_lean);
         }
         alloc_err = e2;
         alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
@@ -670,9 +694,10 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     const double tc1 = now_ms();
     {
         std::atomic<int> bad(-1);
-        const bool job_stats = getenv("PGM_JOB_STATS") != nullptr;                                  // tools only
-        const bool no_helper = getenv("PGM_NO_HELPER") != nullptr;                                  // experiments only
-        const int mode2_min_bands = getenv("PGM_MODE2_BANDS") ? atoi(getenv("PGM_MODE2_BANDS")) : 20;   // experiments only
+        const bool job_stats = tools_env("PGM_JOB_STATS") != nullptr;                               // tools build only
+        const bool no_helper = tools_env("PGM_NO_HELPER") != nullptr;
+        const int mode2_min_bands = tools_env("PGM_MODE2_BANDS") ? atoi(tools_env("PGM_MODE2_BANDS")) : 20;   // tools build only
+        const uint32_t mode2_min_hd = tools_env("PGM_MODE2_HD") ? (uint32_t)atoi(tools_env("PGM_MODE2_HD")) : 32u;
         const uint32_t chunk_jobs = (uint32_t)std::max<size_t>(1, ((size_t)8 << 20) / std::max<size_t>(1, in_base[njobs] / std::max(1u, njobs)));
         std::vector<std::atomic<uint32_t>> chunk_done((njobs + chunk_jobs - 1) / chunk_jobs + 1);
         for (auto &cd : chunk_done) cd.store(0);
@@ -698,9 +723,9 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
                 // shortens its step by a factor of 2-3, and serve the long edges from the cell storage with a prefetch.
                 const uint32_t nb_job = (g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS;
                 // (the helpers address the job's cell storage with 32-bit byte offsets)
-                const bool allow_long = !getenv("PGM_NO_LONG") && (uint64_t)J.nb * J.tsteps * 1024u < (1ull << 32);
+                const bool allow_long = !tools_env("PGM_NO_LONG") && (uint64_t)J.nb * J.tsteps * 1024u < (1ull << 32);
                 const bool has_long = (o.s1.has_long | o.s2.has_long) != 0 && allow_long;
-                J.mode2 = (J.has_extras && (hD >= 32u || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
+                J.mode2 = (J.has_extras && (hD >= mode2_min_hd || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
                 if (J.mode2) {   // (a MODE 2 sweep keeps every on-chip distance of the graphs, whatever the number of entries of a node)
                     while (hD < o.s1.maxd_cap + o.s2.maxd_cap + (uint32_t)PGM_BLOCK) hD *= 2;
                     while (hDX < o.s2.maxd_cap + 1) hDX *= 2;
@@ -825,9 +850,11 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     // Step times (us, measured with the whole batch resident): ~0.45 for a chain-only band (the leaf level is bound by the
     // HBM write bandwidth), ~0.65 with the near window and the far history in the sweeping wavefront, ~0.6 with helpers.
     std::vector<PgmItem> items;
+    std::vector<uint32_t> lean_list;
+    double lean_cost = 0.0, other_cost = 0.0;   // worker-microseconds of the two kernels' queues
     uint32_t capacity = (uint32_t)ctx->prop.multiProcessorCount;
     // persistent workers: one workgroup of 8 wavefronts per CU (it owns the CU's LDS for its sweeps' histories)
-    if (const char *env_c = getenv("PGM_FILL_WORKERS"))   // experiments only
+    if (const char *env_c = tools_env("PGM_FILL_WORKERS"))   // tools build only
         capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount, (uint32_t)std::max(1, atoi(env_c)));
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
@@ -835,23 +862,19 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = tools_env(k); return v ? atof(v) : d; };   // tools build only
         const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
-        const double tau_l = envd("PGM_SIM_TAU_L", 0.15);   // lean sweep: us per step of R rows per lane
+        const double tau_l = envd("PGM_SIM_TAU_L", 0.27);   // lean sweep: us per step of R rows per lane
         size_t total = 0;
         double rmax = 1.0;
-        for (uint32_t i = 0; i < njobs; ++i) {
+        for (uint32_t q = 0; q < njobs; ++q) {
+            const uint32_t i = b->order[q];   // (largest first: the order of the lean queue)
             const PgmJob &J = b->jobs[i];
             const double tau = J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c);     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             const uint32_t group = J.nslots;                     // bands per item, one per wavefront of the worker
-            if (J.lean) {   // one item: the worker's wavefronts cycle over the bands (hand-off through LDS: 72 steps behind each other)
+            if (J.lean) {   // pgm_lean_kernel's queue: a worker's wavefronts cycle over the job's bands (72 steps behind each other), then the walk
                 const double rounds = std::ceil((double)J.nb / PGM_WAVES), first = std::min<double>(J.nb, PGM_WAVES);
-                Item it;
-                it.rem = it.dur = tau_l * (rounds * J.tsteps + (first - 1.0) * 72.0) + 0.15 * (double)(J.n1 + J.n2);
-                it.gap = 0.0;
-                it.job = i; it.band = 0; it.count = (uint32_t)first;
-                per_job[i].push_back(it);
-                rmax = std::max(rmax, it.rem);
-                total += 1;
+                lean_cost += tau_l * (rounds * J.tsteps + (first - 1.0) * 72.0) + 0.04 * (double)(J.n1 + J.n2);
+                lean_list.push_back(i);
                 continue;
             }
             for (uint32_t band = 0; band < J.nb; band += group) {
@@ -867,6 +890,24 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
             }
             total += per_job[i].size();
         }
+        // The CUs are split between the two kernels (one worker per CU in either):
+        for (uint32_t i = 0; i < njobs; ++i) for (const Item &it : per_job[i]) other_cost += it.dur;
+        uint32_t lean_cus = 0;
+        if (!lean_list.empty()) {
+            // the fill kernel's time is the longer of its critical path (rmax) and its queue over its workers; the lean queue
+            // gets the fewest CUs with which it is done within 0.7 of that
+            lean_cus = capacity;
+            if (total != 0) {
+                const uint32_t lo = std::min(4u, capacity - 1u);
+                for (lean_cus = lo; lean_cus + 4u < capacity; ++lean_cus)
+                    if (lean_cost / lean_cus <= 0.7 * std::max(rmax, other_cost / (double)(capacity - lean_cus))) break;
+            }
+            if (const char *v = tools_env("PGM_LEAN_CUS")) lean_cus = std::max(1u, std::min(capacity - (total != 0 ? 1u : 0u), (uint32_t)atoi(v)));
+            lean_cus = std::min<uint32_t>(lean_cus, (uint32_t)lean_list.size());
+        }
+        b->nlean = (uint32_t)lean_list.size();
+        b->nlean_workers = lean_cus;
+        if (total != 0) capacity = std::max(1u, capacity - lean_cus);
         // event simulation: free workers (min-heap of times), ready items (max-heap of remaining paths), pending successors
         typedef std::pair<double, uint32_t> TE;   // (time, job)
         std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
@@ -898,7 +939,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     const double tc4 = now_ms();
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
-    if (getenv("PGM_FILL_TRACE") && items.size()) (void)hipMalloc((void **)&b->d_trace, 176 * items.size());   // 6 words per item + 16 per item for the helper wavefronts
+    if (lean_list.empty()) lean_list.push_back(0u);
+    if (tools_env("PGM_FILL_TRACE") && njobs) (void)hipMalloc((void **)&b->d_trace, 176 * items.size() + 48 * (size_t)njobs);   // 6 words per item + 16 per item for the helper wavefronts, then 6 words per lean job
     if (items.size() > std::max<size_t>(1, total_bands)) {   // (cannot happen: an item holds at least one band)
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, "work list longer than the number of bands");
@@ -907,11 +949,14 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_lean, lean_list.data(), 4 * lean_list.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
     }
     for (int k = 0; k < 5; ++k) (void)hipEventCreate(&b->ev[k]);
+    (void)hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
     if (cprof)
         fprintf(stderr, "    create: sizes %.2f ms, pinned input block %.2f, flatten %.2f, wait for the allocations %.2f (device %.2f, pinned results %.2f), work list %.2f, upload of %.1f MB %.2f\n",
                 tc0 - tcs, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc_alloc, tc_hostalloc, tc4 - tc3, b->in_bytes / 1e6, now_ms() - tc4);
@@ -955,7 +1000,7 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     // results + mappings were written into the pinned block by the kernel itself (PgmJob::hmap1/hmap2/hresult): wait for
     // the stream, then scatter
     int rc = PGM_OK;
-    if (getenv("PGM_FILL_DBG"))   // instrumented kernel variants leave their counters in the device block
+    if (tools_env("PGM_FILL_DBG"))   // instrumented kernel variants leave their counters in the device block
         HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(b->h_flag, b->d_sync, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     // Finished jobs are copied out while the kernel is still running: a job's traceback worker writes the reversed mappings
@@ -979,7 +1024,7 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
         }
         return (int)n;
     };
-    if (!getenv("PGM_FILL_DBG") && !b->d_trace) {
+    if (!tools_env("PGM_FILL_DBG") && !b->d_trace) {
         for (;;) {
             const int n = collect();
             if (n < 0) { (void)hipStreamSynchronize(ctx->stream); return fail(n == -1 ? PGM_ERR_INVALID : PGM_ERR_DEVICE, n == -1 ? "null mapping buffer" : "corrupt result length"); }
@@ -994,18 +1039,23 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
-        std::vector<unsigned long long> tr(22 * (size_t)b->nitems);
-        std::vector<PgmItem> its(b->nitems);
-        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 176 * (size_t)b->nitems, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> tr(22 * (size_t)b->nitems + 6 * (size_t)b->nlean + 1);
+        std::vector<PgmItem> its(std::max(1u, b->nitems));
+        std::vector<uint32_t> lj(std::max(1u, b->nlean));
+        HIPCHK(hipMemcpy(tr.data(), b->d_trace, 176 * (size_t)b->nitems + 48 * (size_t)b->nlean, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(its.data(), b->d_items, sizeof(PgmItem) * b->nitems, hipMemcpyDeviceToHost));
-        if (FILE *f = fopen(getenv("PGM_FILL_TRACE") ? getenv("PGM_FILL_TRACE") : "/dev/null", "wb")) {
-            fwrite(&b->nitems, 4, 1, f); fwrite(its.data(), sizeof(PgmItem), b->nitems, f); fwrite(tr.data(), 8, tr.size(), f); fclose(f);
+        HIPCHK(hipMemcpy(lj.data(), b->d_lean, 4 * (size_t)b->nlean, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(tools_env("PGM_FILL_TRACE") ? tools_env("PGM_FILL_TRACE") : "/dev/null", "wb")) {
+            // nitems, items, 22 words per item; then nlean, the lean jobs in queue order, 6 words per lean job
+            fwrite(&b->nitems, 4, 1, f); fwrite(its.data(), sizeof(PgmItem), b->nitems, f); fwrite(tr.data(), 8, 22 * (size_t)b->nitems, f);
+            fwrite(&b->nlean, 4, 1, f); fwrite(lj.data(), 4, b->nlean, f); fwrite(tr.data() + 22 * (size_t)b->nitems, 8, 6 * (size_t)b->nlean, f);
+            fclose(f);
         }
     }
     for (uint32_t i = 0; i < b->njobs; ++i) {
         PgmJob::Result res;
         memcpy(&res, b->h_out + b->res_off[i], sizeof res);
-        if (res.status == PGM_STATUS_PENDING && !getenv("PGM_FILL_DBG")) return fail(PGM_ERR_DEVICE, "fill kernel: a job's result record was never written");
+        if (res.status == PGM_STATUS_PENDING && !tools_env("PGM_FILL_DBG")) return fail(PGM_ERR_DEVICE, "fill kernel: a job's result record was never written");
         if (res.status != PGM_OK) rc = res.status;
         if (copied[i]) continue;
         out[i].score = res.score;
@@ -1025,8 +1075,11 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
 void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (!b) return;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }   // nothing of the batch is in flight when its buffers go back to the cache
+    if (ctx && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     cache_give(ctx, pgm_ctx::C_IN, b->d_in, b->cap[pgm_ctx::C_IN]);
     cache_give(ctx, pgm_ctx::C_WORK, b->d_work, b->cap[pgm_ctx::C_WORK]);
     cache_give(ctx, pgm_ctx::C_CELLS, b->d_cells, b->cap[pgm_ctx::C_CELLS]);
@@ -1040,6 +1093,12 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
 }
 
 uint64_t pgm_align_batch_cells(const pgm_align_batch *b) { return b ? b->cells : 0; }
+
+int pgm_align_batch_test_stall(pgm_align_batch *b, uint32_t job, uint32_t band, uint32_t spin_limit) {
+    if (!b) return fail(PGM_ERR_INVALID, "null batch");
+    b->test_stall_job = job; b->test_stall_band = band; b->test_spin_limit = spin_limit;
+    return PGM_OK;
+}
 
 int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) {

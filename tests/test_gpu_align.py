@@ -142,20 +142,18 @@ def test_invalid_graphs_are_rejected(ctx):
     assert J.align_graphs_batch(ctx, [good])[0]["status"] == 0
 
 
-def test_handoff_timeout_aborts_the_batch(ctx, monkeypatch):
+def test_handoff_timeout_aborts_the_batch(ctx):
     """PGM_ERR_DEVICE: band 0 of job 0 never publishes its progress (test knob), the band below times out after a
     shortened spin limit, raises the abort flag and every job of the batch reports a device error instead of hanging."""
     import prographmsa_amd as pg
     from prographmsa_amd import jobs as J
     js = [J.random_job(21, 200, 150, skip_frac=0.2), J.random_job(22, 90, 80, skip_frac=0.0, drop_chain_frac=0.0)]
     b = J.Batch(ctx, js)
-    monkeypatch.setenv("PGM_TEST_SPIN_LIMIT", "2000")
-    monkeypatch.setenv("PGM_TEST_STALL", "0:0")
+    pg.check(pg.lib.pgm_align_batch_test_stall(b.handle, 0, 0, 2000))
     b.run()
     rc = pg.lib.pgm_align_batch_fetch(ctx.handle, b.handle, b.cj.out)
     assert rc == pg.PGM_ERR_DEVICE and b"timed out" in pg.lib.pgm_last_error()
-    monkeypatch.delenv("PGM_TEST_SPIN_LIMIT")
-    monkeypatch.delenv("PGM_TEST_STALL")
+    pg.check(pg.lib.pgm_align_batch_test_stall(b.handle, 0xFFFFFFFF, 0, 0))
     b.run()                                               # the same batch runs clean afterwards
     res = b.fetch()
     import oracle_lib

@@ -48,17 +48,21 @@ late = np.argsort(-end)[:12]
 for i in late:
     j, bd = items[i]
     print("  late item %4d: job %3d (%dx%d, extras=%d) band %2d/%2d  start %.0f  band end %.0f  tb end %.0f" % (i, j, sizes[j][0], sizes[j][1], int(jobs[j].g1.e_col.size != jobs[j].g1.n - 1 or jobs[j].g2.e_col.size != jobs[j].g2.n - 1), bd, (sizes[j][0] - 1 + 63) // 64, start[i], bend[i], tend[i]))
-lean = np.array([j.g1.e_col.size == j.g1.n - 1 and j.g2.e_col.size == j.g2.n - 1 for j in jobs])
-li = [i for i in range(n) if tend[i] > 0 and lean[items[i, 0]]]
-if li:   # lean jobs: the chain walker's counters
-    w, v = raw[li, 5], raw[li, 4]
-    wait_us = ((v >> np.uint64(40)) & np.uint64(0xfffff)).astype(float) / 100.0
-    win_us = ((v >> np.uint64(20)) & np.uint64(0xfffff)).astype(float) / 100.0
-    walk_us = (v & np.uint64(0xfffff)).astype(float) / 100.0
-    tot = tend[li] - bend[li]
-    print("lean jobs: %d; wavefront 0 sweeps %.0f us; then %.0f us until every band is done, walk %.0f us (of which window switches %.1f us: %.1f windows, %.1f not prefetched; %.1f loop iterations), publish %.0f us" % (
-        len(li), (bend[li] - start[li]).mean(), wait_us.mean(), walk_us.mean(), win_us.mean(), (w >> np.uint64(32)).astype(float).mean(),
-        ((w >> np.uint64(16)) & np.uint64(0xffff)).astype(float).mean(), (w & np.uint64(0xffff)).astype(float).mean(), (tot - wait_us - walk_us).mean()))
+# lean jobs (pgm_lean_kernel): second section of the dump: nlean, job ids in queue order, 6 words per job
+off2 = 4 + 16 * n + 8 * 22 * n
+if len(buf) >= off2 + 4:
+    nl = int(np.frombuffer(buf, np.uint32, 1, off2)[0])
+    lj = np.frombuffer(buf, np.uint32, nl, off2 + 4)
+    lr = np.frombuffer(buf, np.uint64, 6 * nl, off2 + 4 + 4 * nl).reshape(nl, 6)
+    if nl:
+        ls, lb, lt = (lr[:, 1].astype(float) - t0) / 100.0, (lr[:, 2].astype(float) - t0) / 100.0, (lr[:, 3].astype(float) - t0) / 100.0
+        w, v = lr[:, 5], lr[:, 4]
+        wait_us = ((v >> np.uint64(40)) & np.uint64(0xfffff)).astype(float) / 100.0
+        win_us = ((v >> np.uint64(20)) & np.uint64(0xfffff)).astype(float) / 100.0
+        walk_us = (v & np.uint64(0xfffff)).astype(float) / 100.0
+        print("lean kernel: %d jobs on %d workers, first start %.0f us, last end %.0f us; per job: wavefront 0 sweeps %.0f us, then %.0f us until every band is done, walk %.0f us (window switches %.1f us: %.1f windows, %.1f not prefetched; %.1f loop iterations), publish %.0f us; total %.0f us" % (
+            nl, len(set(lr[:, 0])), ls.min(), lt.max(), (lb - ls).mean(), wait_us.mean(), walk_us.mean(), win_us.mean(), (w >> np.uint64(32)).astype(float).mean(),
+            ((w >> np.uint64(16)) & np.uint64(0xffff)).astype(float).mean(), (w & np.uint64(0xffff)).astype(float).mean(), (lt - lb - wait_us - walk_us).mean(), (lt - ls).mean()))
 tbi = np.where(tend > 0)[0]
 rel = (raw[tbi, 4] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
 stg = (raw[tbi, 4] >> np.uint64(32)).astype(np.float64) / 100.0   # of which: loads -> LDS (the rest is the link pass)
