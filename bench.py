@@ -14,14 +14,16 @@ One "step" = one pass of the hot path over that batch with the inputs resident i
 T = M^T g2) + emission scores + the fill kernel (DP fill of every band and, after a job's last band, its traceback),
 then the result/mapping copy back to the host.
 
-Multi-GPU: one process per GPU, no collective on the data path (torch.distributed only provides the barrier, the
-max-over-ranks clock and the rendezvous store that serves the work queue's ticket counter).
+Multi-GPU: one process per GPU, no collective on the data path and no RCCL anywhere (torch.distributed with the gloo backend
+only provides the barrier, the max-over-ranks clock and the rendezvous store that serves the work queue's ticket counter).
   value              every rank runs the headline batch on its own device (weak scaling of independent batches)
   all_pairs_nw*      STRONG scaling of the all-pairs stage (DistanceFactoryAlign): the alignPair jobs of the family, cut into
                      tiles (longest first) that the ranks pull from one atomic ticket counter (prographmsa_amd/farm.py, the
                      process-per-GPU twin of the product's farm in host/distance.cpp); 256 x 1000 and 1024 x 600 families
-  progressive_strong STRONG scaling of the progressive pass: the 255 captured jobs dealt to the ranks (longest first);
-                     bounded by the root job's critical path, reported as measured
+  progressive_strong STRONG scaling of the progressive pass: (a) the product driver itself on all N GPUs (rank 0 runs `pgmsa` with
+                     PGM_DEVICES = every rank's device: the jobs of a guide-tree level, the leaves and the merges are dealt to one
+                     context per GPU, host/graph_align.cpp farm_shards), (b) the 255 captured jobs dealt to the ranks (longest
+                     first); both bounded by the root job's critical path, reported as measured
 """
 import argparse
 import json
@@ -111,7 +113,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")   # barrier, clock reduction and the work queue's store: control path only, no RCCL
 
     import ctypes as C
     import hashlib
@@ -132,14 +134,14 @@ def main():
 
     def max_over_ranks(x):
         if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x
 
     def sum_over_ranks(x):
         if world > 1:
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return float(t.item())
         return x
@@ -160,7 +162,7 @@ def main():
         js = J.load_jobs(dump)
         os.remove(dump)
         # the driver's own times come from further runs without the job dump (writing the jobs to disk is not part of the
-        # product): the best of three by progressive_s, all three listed (a pass is 50-150 ms, and this pool's hosts stall a GPU
+        # product): the median of three by progressive_s, all three listed (a pass is 50-150 ms, and this pool's hosts stall a GPU
         # wait for ~20 ms about once a second — on some boxes several times per pass: DESIGN §4)
         runs = []
         if rank != 0:   # (only rank 0 reports the driver's times)
@@ -176,7 +178,7 @@ def main():
             st = json.loads([ln for ln in r2.stderr.splitlines() if ln.startswith('{"backend"')][-1])
             st["wall_s"] = round(wall, 3)
             runs.append(st)
-        st = sorted(runs, key=lambda q: q["progressive_s"])[0]
+        st = sorted(runs, key=lambda q: q["progressive_s"])[1]   # the median of the three runs
         st["progressive_s_of_3_runs"] = sorted(q["progressive_s"] for q in runs)
         return js, st, hashlib.md5(r.stdout.encode()).hexdigest()
 
@@ -217,27 +219,33 @@ def main():
     if args.warmup > 0:
         check = batch.fetch()   # results of the last warm-up step as Python objects (sanity check)
         assert all(r["status"] == 0 and len(r["map1"]) > 0 for r in check)
+    batch.stage_times(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run()          # pgm_align_batch_run: prep + emission + fill/traceback kernels
+        batch.run()          # pgm_align_batch_run: prep + emission + fill (+ lean) / traceback kernels
         batch.fetch_raw()    # pgm_align_batch_fetch: wait, D2H of scores and mappings into the caller's buffers
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     total_cells = sum_over_ranks(float(cells) * args.steps)
 
-    # ---- roofline of the dominant kernel (pgm_fill_kernel: DP fill + tracebacks), HIP events on the library's stream ----
-    reps = [batch.time(1) for _ in range(7)]          # per-stage device times, median of 7 single runs
-    ms_prep, ms_emis, ms_fill = (sorted(r[k] for r in reps)[3] for k in range(3))
+    # ---- roofline of the dominant kernel (pgm_fill_kernel beside pgm_lean_kernel: DP fill + tracebacks): HIP events on the
+    # library's stream, recorded by every launch of the timed loop above and averaged over exactly those launches ----
+    ms_prep, ms_emis, ms_fill, n_timed = batch.stage_times(reset=True)
+    assert n_timed == args.steps
     alg_bytes = 16.0 * cells            # one float4 {M,X,W,Y} store per cell; S is materialised by the emission
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
-    traffic, pmc_name = None, "profiles/r2_pmc.json"
+    traffic, pmc_name = None, "profiles/r3_pmc.json"
     pmc_path = os.path.join(ROOT, pmc_name)
     if headline and os.path.exists(pmc_path):
-        pmc = next((v for k, v in json.load(open(pmc_path)).items() if k.startswith("pgm_fill_kernel")), {})
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            traffic = round((2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0)
+        allp = json.load(open(pmc_path))
+        traffic = 0.0   # the fill kernel and the lean jobs' kernel that runs beside it
+        for kn in ("pgm_fill_kernel", "pgm_lean_kernel"):
+            pmc = next((v for k, v in allp.items() if k.startswith(kn)), {})
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic += (2.0 * pmc["FETCH_SIZE"]["mean_kb"] + pmc["WRITE_SIZE"]["mean_kb"]) * 1024.0
+        traffic = round(traffic) if traffic else None
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
 
     def valu_roofline(kernel, launch_ms):
@@ -255,11 +263,42 @@ def main():
                 "wave_cycles_split": {k: round(c[k]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 3) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c},
                 "source": pmc_name + " (SQ pass), launch time live (HIP events)"}
 
-    roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "pgm_fill_kernel (+ pgm_lean_kernel beside it on a second stream)", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes,
-                "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE)",
-                "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4)},
+                "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, both kernels)",
+                "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4),
+                       "sum": round(ms_prep + ms_emis + ms_fill, 4), "source": "HIP events of the %d timed steps themselves (pgm_align_batch_stage_times)" % n_timed},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
+
+    # ---- the two other lines SURVEY section 7 asks for: the leaf level alone, and the product's whole progressive pass --------
+    def is_chain(g):
+        return g.r_col is None and g.e_col.size == g.n - 1 and bool(np.all(g.e_col == np.arange(g.n - 1, dtype=np.uint32))) and bool(np.all(g.e_val != 0))
+    leaf_jobs = [j for j in jobs if is_chain(j.g1) and is_chain(j.g2)]
+    roofline_leaf = None
+    if leaf_jobs:
+        lb = J.Batch(ctx, leaf_jobs)
+        for _ in range(3):
+            lb.run(); lb.fetch_raw()
+        lb.stage_times(reset=True)
+        tl = time.perf_counter()
+        nrep = max(20, args.steps // 4)
+        for _ in range(nrep):
+            lb.run(); lb.fetch_raw()
+        ldt = (time.perf_counter() - tl) / nrep
+        lp, le, lf, _n = lb.stage_times(reset=True)
+        lcells = lb.cells
+        roofline_leaf = {"bound": "hbm", "kernel": "pgm_lean_kernel", "jobs": len(leaf_jobs), "cells": lcells, "ms_per_step": round(ldt * 1e3, 4),
+                         "ms": {"prep": round(lp, 4), "emission": round(le, 4), "fill_and_traceback": round(lf, 4)},
+                         "gcups": round(lcells / (lf * 1e-3) / 1e9, 2), "achieved": round(16.0 * lcells / (lf * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(16.0 * lcells / (lf * 1e-3) / 8e12, 5),
+                         "note": "the chain-only jobs of the pass (sequence graph against sequence graph: the guide tree's leaf level) as a batch of their own; "
+                                 "algorithmic bytes as for the headline (16 B per cell); these jobs keep 4 decision bits per cell instead of the four floats "
+                                 "(DESIGN section 3.1), so the bytes actually moved are far fewer: S read 4 B + 0.5 B per cell"}
+        lb.close()
+    roofline_pass = {"bound": "hbm", "what": "the product driver's whole progressive pass (pgmsa --fasta -m -t: 8 level-batched calls, host merges, H2D / D2H)",
+                     "progressive_s": stats["progressive_s"], "gcups": round(cells / stats["progressive_s"] / 1e9, 3),
+                     "achieved": round(16.0 * cells / stats["progressive_s"] / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(16.0 * cells / stats["progressive_s"] / 8e12, 5)}
 
     # ---- strong scaling of the progressive pass: the same jobs dealt to the ranks (longest first), one pass ---------------
     prog_strong = None
@@ -275,7 +314,24 @@ def main():
             sb.fetch_raw()
         barrier()
         sdt = max_over_ranks(time.perf_counter() - t0)
-        prog_strong = {"jobs_per_rank": [len(s) for s in shards], "ms_per_pass": round(sdt / args.steps * 1e3, 4),
+        product = None
+        barrier()
+        if rank == 0:   # the product driver's own farm: one context per GPU inside ONE process (the other ranks wait at the barrier)
+            envp = dict(os.environ, PGM_DEVICES=",".join(str(d) for d in range(world)))
+            envp.pop("PGM_DEVICE", None)
+            fa0 = os.path.join(tmp, "c3.fa")
+            runs = []
+            for _ in range(3):
+                rp = subprocess.run([pg.PGMSA_PATH, "--fasta", "-m"] + tree_args + ["--stats", fa0], capture_output=True, text=True, env=envp)
+                if rp.returncode == 0:
+                    stp = json.loads([ln for ln in rp.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+                    runs.append((stp["progressive_s"], stp.get("farm_level_workers"), hashlib.md5(rp.stdout.encode()).hexdigest() == out_md5))
+            if runs:
+                runs.sort()
+                product = {"cmd": "pgmsa --fasta -m -t (PGM_DEVICES = all %d GPUs)" % world, "progressive_s_of_3_runs": [r[0] for r in runs], "progressive_s": runs[1 if len(runs) > 2 else 0][0],
+                           "farm_level_workers": runs[0][1], "fasta_identical_to_one_gpu": all(r[2] for r in runs), "one_gpu_progressive_s": stats["progressive_s"]}
+        barrier()
+        prog_strong = {"product_farm": product, "jobs_per_rank": [len(s) for s in shards], "ms_per_pass": round(sdt / args.steps * 1e3, 4),
                        "gcups": round(cells * args.steps / sdt / 1e9, 3), "scaling": "strong",
                        "note": "one pass = all 255 jobs across the ranks; the root job (1.7 % of the cells) is a single critical path"}
         sb.close()
@@ -327,6 +383,7 @@ def main():
             dist.all_gather_object(tiles_per_rank, my_tiles)
         return {"pairs_total": npairs, "cells_total": tot, "tile_pairs": tile, "tiles": ntiles, "tiles_per_rank": tiles_per_rank,
                 "wall_s": round(wall, 4), "gcups_wall": round(tot / wall / 1e9, 2), "rank0_kernel_ms": round(kernel_ms[0], 3),
+                "rank0_wall_over_kernel": round(wall * 1e3 / max(kernel_ms[0], 1e-9), 3), "rank0_fixed_ms_per_call": round((wall * 1e3 - kernel_ms[0]) / max(my_tiles, 1), 3),
                 "rank0_kernel_gcups": round(my_cells / max(kernel_ms[0], 1e-9) / 1e6, 2), "scaling": "strong",
                 "note": "tiles of alignPair jobs (longest first) pulled by the ranks from one ticket counter; whole pgm_nw_pairs_batch calls "
                         "incl. H2D of the sequences and D2H of the 400-int count matrices; 2 direction bits/cell stored "
@@ -397,15 +454,18 @@ def main():
             js, st, md5 = capture(text, flags, name)
             b2 = J.Batch(ctx, js)
             b2.run(); b2.fetch_raw()
+            b2.stage_times(reset=True)
             t0 = time.perf_counter()
             for _ in range(40):
                 b2.run()
                 b2.fetch_raw()
             d2 = (time.perf_counter() - t0) / 40
-            tm = sorted(b2.time(1) for _ in range(3))[1]
+            tm = b2.stage_times(reset=True)[:3]
             configs[name] = {"jobs": len(js), "cells": b2.cells, "dim": js[0].g1.dim, "ms_per_pass": round(d2 * 1e3, 3),
                              "gcups": round(b2.cells / d2 / 1e9, 3), "ms": {"prep": round(tm[0], 3), "emission": round(tm[1], 3), "fill_and_traceback": round(tm[2], 3)},
                              "fill_frac_of_hbm_roofline": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 4),
+                             "roofline": {"bound": "hbm", "achieved": round(16.0 * b2.cells / (tm[2] * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                                          "frac": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 5), "traffic": None},
                              "pgmsa": {"wall_s": st["wall_s"], "init_s": st.get("init_s"), "progressive_s": st["progressive_s"], "align_call_s": st["align_s"]},
                              "fasta_identical_to_reference": md5 == md5s.get(ref_md5), "reference_one_pass_s": ref_s,
                              "note": "jobs of one progressive pass captured from the product driver, inputs resident in HBM; "
@@ -424,6 +484,8 @@ def main():
                                    "(%.3e DP cells) per GPU, inputs resident in HBM" % (args.nseq, args.len, len(jobs), cells),
                        "headline": headline, "device": devname, "cus": cus, "jobs": len(jobs), "cells_per_step": cells},
             "roofline": roofline,
+            "roofline_leaf": roofline_leaf,
+            "roofline_pass": roofline_pass,
             "all_pairs_nw": nw,
             "all_pairs_nw_1024x600": nw_big,
             "progressive_strong": prog_strong,
@@ -432,7 +494,7 @@ def main():
             "end_to_end": {"pgmsa_wall_s": stats["wall_s"], "init_s": stats.get("init_s"), "progressive_s": stats["progressive_s"], "align_call_s": stats["align_s"],
                            "fasta_identical_to_reference": (out_md5 == md5s.get("c3.out.fa")) if headline else None,
                            "progressive_s_of_3_runs": stats.get("progressive_s_of_3_runs"),
-                           "note": "the best of three runs of the product driver outside the timed region (without the job dump; all three under progressive_s_of_3_runs); progressive_s incl. host merges, H2D/D2H and allocations, init_s = HIP start-up + code object load (before the stage clocks start)",
+                           "note": "the median of three runs of the product driver outside the timed region (without the job dump; all three under progressive_s_of_3_runs); progressive_s incl. host merges, H2D/D2H and allocations, init_s = HIP start-up + code object load (before the stage clocks start)",
                            "default_flow": default_flow},
         }
         if world == 1 and not args.no_cpu_baseline:

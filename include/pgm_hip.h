@@ -124,6 +124,11 @@ uint64_t pgm_align_batch_cells(const pgm_align_batch *b);
  * band walks that job's path), so ms_fill includes them and ms_traceback is ~0. */
 int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_prep,
                          float *ms_emission, float *ms_fill, float *ms_traceback);
+/* Mean device time (ms, HIP events on the library's stream) of the three stages — prep, emission scores, fill incl. the lean
+ * jobs' kernel and all tracebacks — over the launches of pgm_align_batch_run that pgm_align_batch_fetch has completed since the
+ * last reset, and their number: the stage times of exactly the steps a caller timed (bench.py), not of extra launches. */
+int pgm_align_batch_stage_times(pgm_align_batch *b, int reset, float *ms_prep, float *ms_emission, float *ms_fill,
+                                uint32_t *launches);
 /* Test hook for the hand-off time-out path: in the following launches band `band` of job `job` never publishes its progress
  * and a wavefront that waits for another gives up after `spin_limit` polls (0: the default); the band below then times out,
  * raises the batch's abort flag and every unfinished job reports PGM_ERR_DEVICE.  job = 0xFFFFFFFF switches it off. */

@@ -22,11 +22,11 @@ namespace {
 struct OracleBackend : Backend {
     const char *name() const override { return "oracle"; }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
-                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) override {
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int) override {
         pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out);
     }
-    // PGM_FARM_WORKERS=k: the all-pairs farm of the host scaffolding runs with k host threads over this (stateless,
-    // re-entrant) CPU oracle: the 1-vs-k-workers identity test of tests/test_cpu_host.py
+    // PGM_FARM_WORKERS=k: the farms of the host scaffolding (all-pairs tiles, jobs of a guide-tree level, leaves) run with k
+    // host threads over this (stateless, re-entrant) CPU oracle: the 1-vs-k-workers identity tests of tests/test_cpu_host.py
     int workers() const override { const char *e = getenv("PGM_FARM_WORKERS"); return e ? std::max(1, atoi(e)) : 1; }
     void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
                         const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
@@ -36,7 +36,7 @@ struct OracleBackend : Backend {
     }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                 const double *tau, const double *pi, const double *p_uniform, double *out,
-                                const uint64_t *out_offs) override {
+                                const uint64_t *out_offs, int) override {
         for (uint32_t s = 0; s < nseq; ++s)
             pgmo_csprofile_create((uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(), lib.centre().data(),
                                   lib.priors().data(), syms + offs[s], offs[s + 1] - offs[s], tau[s], pi,

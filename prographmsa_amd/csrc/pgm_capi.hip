@@ -157,6 +157,9 @@ struct pgm_align_batch {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // stream -> stream2 after the emission kernel, stream2 -> stream after the lean kernel
     unsigned long long *d_trace = nullptr;   // PGM_FILL_TRACE=file: per-item timeline, written by fetch (tools only)
     uint32_t test_spin_limit = 0, test_stall_job = 0xFFFFFFFFu, test_stall_band = 0;   // pgm_align_batch_test_stall
+    double acc_ms[3] = {0, 0, 0};     // device time of prep / emission / fill (+ lean kernel + tracebacks) summed over the launches fetched since the last reset
+    uint32_t acc_n = 0;
+    bool ev_pending = false;          // the last launch recorded its stage events and they have not been read yet
     uint32_t nitems = 0, lean_rshift = PGM_LEAN_RSHIFT_DEFAULT;
     uint32_t nworkers = 0, maxnblk = 0;
     PgmJob *d_jobs = nullptr;
@@ -968,7 +971,8 @@ int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b) {
     if (!ctx || !b) return fail(PGM_ERR_INVALID, "null argument");
     if (b->njobs == 0) return PGM_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(launch_all(ctx, b, false));
+    HIPCHK(launch_all(ctx, b, true));   // (stage events: four event records per launch, read by fetch once the stream has completed)
+    b->ev_pending = true;
     return PGM_OK;
 }
 
@@ -979,6 +983,7 @@ int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_p
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps && b->njobs; ++r) {
         HIPCHK(launch_all(ctx, b, true));
+        b->ev_pending = false;
         HIPCHK(hipEventSynchronize(b->ev[4]));
         for (int k = 0; k < 4; ++k) {
             float ms = 0;
@@ -1035,6 +1040,14 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (b->ev_pending) {   // stage times of the launch just completed (pgm_align_batch_stage_times)
+        b->ev_pending = false;
+        float ms[3] = {0, 0, 0};
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) ok = ok && hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]) == hipSuccess;
+        if (ok) { for (int k = 0; k < 3; ++k) b->acc_ms[k] += ms[k]; ++b->acc_n; }
+        else (void)hipGetLastError();
+    }
     const int aborted = *b->h_flag;
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
@@ -1093,6 +1106,17 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
 }
 
 uint64_t pgm_align_batch_cells(const pgm_align_batch *b) { return b ? b->cells : 0; }
+
+int pgm_align_batch_stage_times(pgm_align_batch *b, int reset, float *ms_prep, float *ms_emission, float *ms_fill, uint32_t *launches) {
+    if (!b) return fail(PGM_ERR_INVALID, "null batch");
+    const double n = b->acc_n ? (double)b->acc_n : 1.0;
+    if (ms_prep) *ms_prep = (float)(b->acc_ms[0] / n);
+    if (ms_emission) *ms_emission = (float)(b->acc_ms[1] / n);
+    if (ms_fill) *ms_fill = (float)(b->acc_ms[2] / n);
+    if (launches) *launches = b->acc_n;
+    if (reset) { b->acc_ms[0] = b->acc_ms[1] = b->acc_ms[2] = 0; b->acc_n = 0; }
+    return PGM_OK;
+}
 
 int pgm_align_batch_test_stall(pgm_align_batch *b, uint32_t job, uint32_t band, uint32_t spin_limit) {
     if (!b) return fail(PGM_ERR_INVALID, "null batch");

@@ -11,11 +11,11 @@ namespace pgm {
 namespace {
 struct HipBackend : Backend {
     // One context per device.  PGM_DEVICES="0,2,5" lists them explicitly, PGM_DEVICE=k selects one (what a one-process-
-    // per-GPU launcher sets), otherwise every visible device is used: context 0 runs the alignGraphs batches and the
-    // context profiles, all of them serve the all-pairs farm (computePwDistances, one host thread per context).
+    // per-GPU launcher sets), otherwise every visible device is used.  Every batch call runs on the context the caller names
+    // (`worker`): the host code deals a batch's independent units — jobs of a guide-tree level, leaves, merges, sequence
+    // pairs — to the contexts, one host thread each (farm_shards / computePwDistances).
     std::vector<pgm_ctx *> ctxs;
-    pgm_ctx *ctx = nullptr;
-    const CSProfile *loaded = nullptr;
+    std::vector<const CSProfile *> loaded;   // the profile library resident on context w
     HipBackend() {
         std::vector<int> devs;
         if (const char *e = getenv("PGM_DEVICES")) {
@@ -32,14 +32,15 @@ struct HipBackend : Backend {
                 error("libpgm_hip: cannot create a context on device %d: %s", d, pgm_last_error());
             ctxs.push_back(c);
         }
-        ctx = ctxs[0];
+        loaded.assign(ctxs.size(), nullptr);
     }
+    pgm_ctx *ctx_of(int worker) const { return ctxs[(size_t)worker % ctxs.size()]; }
     ~HipBackend() override { for (pgm_ctx *c : ctxs) pgm_ctx_destroy(c); }
     const char *name() const override { return "hip"; }
     int workers() const override { return (int)ctxs.size(); }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
-                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) override {
-        int rc = pgm_align_graphs_batch(ctx, njobs, g1, g2, model, scores, out);
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int worker) override {
+        int rc = pgm_align_graphs_batch(ctx_of(worker), njobs, g1, g2, model, scores, out);
         if (rc != PGM_OK && rc != PGM_ERR_BACKTRACK) error("pgm_align_graphs_batch failed (%d): %s", rc, pgm_last_error());
     }
     void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
@@ -55,24 +56,26 @@ struct HipBackend : Backend {
         return true;
     }
     bool prealigned_counts_batch(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
-                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps) override {
-        int rc = pgm_prealigned_counts_batch(ctx, dim, nrows, ncols, rows, npairs, pi, pj, counts, gaps);
+                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps, int worker) override {
+        int rc = pgm_prealigned_counts_batch(ctx_of(worker), dim, nrows, ncols, rows, npairs, pi, pj, counts, gaps);
         if (rc != PGM_OK) error("pgm_prealigned_counts_batch failed (%d): %s", rc, pgm_last_error());
         return true;
     }
-    bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs) override {
-        int rc = pgm_merge_profiles_batch(ctx, njobs, jobs);
+    bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs, int worker) override {
+        int rc = pgm_merge_profiles_batch(ctx_of(worker), njobs, jobs);
         if (rc != PGM_OK) error("pgm_merge_profiles_batch failed (%d): %s", rc, pgm_last_error());
         return true;
     }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                 const double *tau, const double *pi, const double *p_uniform, double *out,
-                                const uint64_t *out_offs) override {
-        if (loaded != &lib) {
+                                const uint64_t *out_offs, int worker) override {
+        pgm_ctx *ctx = ctx_of(worker);
+        const size_t slot = (size_t)worker % ctxs.size();
+        if (loaded[slot] != &lib) {
             int rc = pgm_csprofile_load(ctx, (uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(),
                                         lib.centre().data(), lib.priors().data());
             if (rc != PGM_OK) error("pgm_csprofile_load failed (%d): %s", rc, pgm_last_error());
-            loaded = &lib;
+            loaded[slot] = &lib;
         }
         int rc = pgm_csprofile_create_batch(ctx, nseq, syms, offs, tau, pi, p_uniform, out, out_offs);
         if (rc != PGM_OK) error("pgm_csprofile_create_batch failed (%d): %s", rc, pgm_last_error());

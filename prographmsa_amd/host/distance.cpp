@@ -384,7 +384,22 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
                 const int v = alphabet.isGap(c) ? -1 : alphabet.value(c);
                 mat[(size_t)i * L + k] = (int8_t)(alphabet.isGap(c) ? -1 : (v < 0 ? -2 : v));
             }
-        done = be.prealigned_counts_batch(D, n, (uint32_t)L, mat.data(), np, pi.data(), pj.data(), counts.data(), gaps.data());
+        {
+            // every pair costs the same (one scan of the columns): contiguous ranges of pairs, one per device context
+            const int nw = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, be.workers()), np));
+            std::vector<char> ok((size_t)nw, 0);
+            auto part = [&](int w) {
+                const uint32_t p0 = (uint32_t)((uint64_t)np * (uint32_t)w / (uint32_t)nw), p1 = (uint32_t)((uint64_t)np * ((uint32_t)w + 1u) / (uint32_t)nw);
+                ok[(size_t)w] = (p1 == p0 || be.prealigned_counts_batch(D, n, (uint32_t)L, mat.data(), p1 - p0, pi.data() + p0, pj.data() + p0,
+                                                                       counts.data() + (size_t)p0 * D * D, gaps.data() + p0, w)) ? 1 : 0;
+            };
+            std::vector<std::thread> th;
+            for (int w = 1; w < nw; ++w) th.emplace_back(part, w);
+            part(0);
+            for (auto &t : th) t.join();
+            done = true;
+            for (char c : ok) done = done && c;
+        }
         be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (!done) {

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 
@@ -116,6 +117,31 @@ static void dump_job(const pgm_graph &g1, const pgm_graph &g2, const pgm_model &
     fclose(f);
 }
 
+std::vector<std::vector<uint32_t>> farm_shards(const std::vector<uint64_t> &cost, int nw) {
+    const uint32_t n = (uint32_t)cost.size();
+    nw = std::max(1, std::min<int>(nw, (int)std::max(1u, n)));
+    std::vector<std::vector<uint32_t>> sh((size_t)nw);
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    std::vector<uint64_t> load((size_t)nw, 0);
+    for (uint32_t i : order) {
+        size_t w = 0;
+        for (size_t k = 1; k < load.size(); ++k) if (load[k] < load[w]) w = k;
+        sh[w].push_back(i);
+        load[w] += std::max<uint64_t>(cost[i], 1);
+    }
+    while (sh.size() > 1 && sh.back().empty()) sh.pop_back();
+    return sh;
+}
+
+void farm_run(const std::vector<std::vector<uint32_t>> &shards, const std::function<void(int)> &fn) {
+    std::vector<std::thread> th;
+    for (size_t w = 1; w < shards.size(); ++w) if (!shards[w].empty()) th.emplace_back(fn, (int)w);
+    if (!shards.empty() && !shards[0].empty()) fn(0);
+    for (auto &t : th) t.join();
+}
+
 std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1, const std::vector<const Graph *> &g2,
                                               const std::vector<const Model *> &model) {
     const uint32_t n = (uint32_t)g1.size();
@@ -146,7 +172,27 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
         if (!g_dump_path.empty()) dump_job(f1[i], f2[i], fm[i], sc[i]);
     }
     auto t0 = std::chrono::steady_clock::now();
-    be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data());
+    // The jobs of a level are independent (sibling subtrees, ProgressiveAlignment.cpp:50-51): with several device contexts
+    // they are dealt to the workers by DP cells, longest first; every worker runs its shard as one batch on its own context.
+    std::vector<uint64_t> cost(n);
+    for (uint32_t i = 0; i < n; ++i) cost[i] = (uint64_t)g1[i]->size() * g2[i]->size();
+    const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
+    if (shards.size() <= 1) {
+        be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data(), 0);
+    } else {
+        farm_run(shards, [&](int w) {
+            const std::vector<uint32_t> &sh = shards[(size_t)w];
+            const uint32_t m = (uint32_t)sh.size();
+            std::vector<const pgm_graph *> q1(m), q2(m);
+            std::vector<const pgm_model *> qm(m);
+            std::vector<pgm_scores> qs(m);
+            std::vector<pgm_align_out> qo(m);
+            for (uint32_t k = 0; k < m; ++k) { q1[k] = p1[sh[k]]; q2[k] = p2[sh[k]]; qm[k] = pm[sh[k]]; qs[k] = sc[sh[k]]; qo[k] = out[sh[k]]; }
+            be.align_graphs_batch(m, q1.data(), q2.data(), qm.data(), qs.data(), qo.data(), w);
+            for (uint32_t k = 0; k < m; ++k) out[sh[k]] = qo[k];
+        });
+    }
+    be.farm_level_workers = std::max(be.farm_level_workers, (int)shards.size());
     be.seconds_align += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t i = 0; i < n; ++i) {
         if (out[i].status != PGM_OK) error("backtracking failed");  // GraphAlign.h:410

@@ -214,31 +214,39 @@ pgm_scores DynProgScores(const Graph &g1, const Graph &g2, const Model &model); 
 struct Backend {
     virtual ~Backend() {}
     virtual const char *name() const = 0;
+    // Every batch call takes the worker (device context) it runs on, 0 <= worker < workers(); calls with different workers may
+    // run concurrently.  The host code shards a batch's independent units over the workers (farm_shards below): jobs of a
+    // guide-tree level, leaves, merges, sequence pairs — no exchange between workers, results independent of their number.
     virtual void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                                     const pgm_model *const *model, const pgm_scores *scores,
-                                    pgm_align_out *out) = 0;
-    // `worker` selects the device context (0 <= worker < workers()); calls with different workers may run concurrently
+                                    pgm_align_out *out, int worker = 0) = 0;
     virtual void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
                                 const int8_t *syms, const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps, int worker = 0) = 0;
-    // number of device contexts the all-pairs farm (computePwDistances) may drive, one host thread each
+    // number of device contexts the farms may drive, one host thread each
     virtual int workers() const { return 1; }
     // batched DistanceFactoryML::computeDistance and the pair counts of an alignment on the device;
     // false = this backend has no such kernel (the host estimator is used)
     virtual bool mldist_batch(const pgm_mldist_model &, uint32_t, const int32_t *, const uint32_t *, const double *, double *, double *, int = 0) { return false; }
-    virtual bool prealigned_counts_batch(uint32_t, uint32_t, uint32_t, const int8_t *, uint32_t, const uint32_t *, const uint32_t *, int32_t *, uint32_t *) { return false; }
+    virtual bool prealigned_counts_batch(uint32_t, uint32_t, uint32_t, const int8_t *, uint32_t, const uint32_t *, const uint32_t *, int32_t *, uint32_t *, int = 0) { return false; }
     // node profiles of a batch of merged graphs on the device (numeric part); false = host arithmetic
-    virtual bool merge_profiles_batch(uint32_t, const pgm_merge_job *) { return false; }
+    virtual bool merge_profiles_batch(uint32_t, const pgm_merge_job *, int = 0) { return false; }
     double seconds_merge_profiles = 0;
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
-                                        const uint64_t *out_offs) = 0;
+                                        const uint64_t *out_offs, int worker = 0) = 0;
     int farm_workers = 0, farm_tiles = 0;   // what the last all-pairs farm used (logs / --stats)
+    int farm_level_workers = 0, farm_leaf_workers = 0;   // most workers a guide-tree level's jobs / the leaves' profiles were dealt to
     uint64_t cells_aligned = 0;   // Σ (n1-2)(n2-2)
     uint64_t cells_nw = 0;        // Σ L1*L2
     double seconds_align = 0, seconds_nw = 0, seconds_mldist = 0;
 };
 Backend &default_backend();            // defined by exactly one backend_*.cpp linked into the program
+// Units of a batch dealt to `nw` workers: longest first, each to the worker with the least load so far (ties: the lowest
+// worker).  Deterministic; shard w lists its units in descending cost.  With one worker or one unit: everything to worker 0.
+std::vector<std::vector<uint32_t>> farm_shards(const std::vector<uint64_t> &cost, int nw);
+// runs fn(w) for every non-empty shard, worker 0 on the calling thread, the others on threads of their own
+void farm_run(const std::vector<std::vector<uint32_t>> &shards, const std::function<void(int)> &fn);
 void set_job_dump(const std::string &path);  // if set, every alignGraphs job is appended to this file
 void set_dist_dump(const std::string &path); // if set, every distance matrix TreeNJ estimates is appended (dim, D, V as raw doubles)
 

@@ -128,8 +128,37 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             }
         }
         std::vector<double> out(out_offs[ns]);
-        default_backend().csprofile_create_batch(*csprofile, ns, syms.data(), offs.data(), tau.data(), pi.data(),
-                                                 p_uniform.data(), out.data(), out_offs.data());
+        {
+            // the leaves are independent (SequenceGraph.h:111-121): dealt to the device contexts by length
+            Backend &be = default_backend();
+            std::vector<uint64_t> cost(ns);
+            for (uint32_t s = 0; s < ns; ++s) cost[s] = offs[s + 1] - offs[s];
+            const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
+            if (shards.size() <= 1) {
+                be.csprofile_create_batch(*csprofile, ns, syms.data(), offs.data(), tau.data(), pi.data(), p_uniform.data(), out.data(), out_offs.data(), 0);
+            } else {
+                farm_run(shards, [&](int w) {
+                    const std::vector<uint32_t> &sh = shards[(size_t)w];
+                    const uint32_t m = (uint32_t)sh.size();
+                    std::vector<int8_t> sy;
+                    std::vector<uint32_t> of(m + 1, 0);
+                    std::vector<uint64_t> oo(m + 1, 0);
+                    std::vector<double> ta(m), pu((size_t)m * 20);
+                    for (uint32_t k = 0; k < m; ++k) {
+                        const uint32_t s = sh[k];
+                        sy.insert(sy.end(), syms.begin() + offs[s], syms.begin() + offs[s + 1]);
+                        of[k + 1] = (uint32_t)sy.size();
+                        oo[k + 1] = oo[k] + (out_offs[s + 1] - out_offs[s]);
+                        ta[k] = tau[s];
+                        std::copy(p_uniform.begin() + (size_t)s * 20, p_uniform.begin() + (size_t)s * 20 + 20, pu.begin() + (size_t)k * 20);
+                    }
+                    std::vector<double> o(oo[m]);
+                    be.csprofile_create_batch(*csprofile, m, sy.data(), of.data(), ta.data(), pi.data(), pu.data(), o.data(), oo.data(), w);
+                    for (uint32_t k = 0; k < m; ++k) std::copy(o.begin() + oo[k], o.begin() + oo[k + 1], out.begin() + out_offs[sh[k]]);
+                });
+            }
+            be.farm_leaf_workers = std::max(be.farm_leaf_workers, (int)shards.size());
+        }
         for (uint32_t s = 0; s < ns; ++s) {
             Node &nd = nodes[leaves[s]];
             index_t nn = (index_t)((out_offs[s + 1] - out_offs[s]) / 20);
@@ -196,7 +225,26 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 j.profiles = profiles[k].data();
             }
             const auto tm0 = std::chrono::steady_clock::now();
-            on_device = default_backend().merge_profiles_batch((uint32_t)L, mj.data());
+            {
+                // the merges of a level are independent: dealt to the device contexts by the size of the merged graph
+                Backend &be = default_backend();
+                std::vector<uint64_t> cost(L);
+                for (size_t k = 0; k < L; ++k) cost[k] = mj[k].nnodes;
+                const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
+                if (shards.size() <= 1) {
+                    on_device = be.merge_profiles_batch((uint32_t)L, mj.data(), 0);
+                } else {
+                    std::vector<char> ok(shards.size(), 0);
+                    farm_run(shards, [&](int w) {
+                        const std::vector<uint32_t> &sh = shards[(size_t)w];
+                        std::vector<pgm_merge_job> q(sh.size());
+                        for (size_t k = 0; k < sh.size(); ++k) q[k] = mj[sh[k]];
+                        ok[(size_t)w] = be.merge_profiles_batch((uint32_t)q.size(), q.data(), w) ? 1 : 0;
+                    });
+                    on_device = true;
+                    for (size_t w = 0; w < shards.size(); ++w) on_device = on_device && (ok[w] || shards[w].empty());
+                }
+            }
             default_backend().seconds_merge_profiles += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
         }
         const auto tq1 = std::chrono::steady_clock::now();

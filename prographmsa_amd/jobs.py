@@ -165,6 +165,12 @@ class Batch:
         check(lib.pgm_align_batch_time(self.ctx.handle, self.handle, reps, C.byref(a), C.byref(e), C.byref(b), C.byref(c)))
         return a.value, e.value, b.value, c.value
 
+    def stage_times(self, reset=True):
+        """Mean (prep, emission, fill) device ms over the launches fetched since the last reset, and how many those were."""
+        a, e, f, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
+        check(lib.pgm_align_batch_stage_times(self.handle, 1 if reset else 0, C.byref(a), C.byref(e), C.byref(f), C.byref(n)))
+        return a.value, e.value, f.value, n.value
+
     def read_matrices(self, job):
         j = self.cj.jobs[job]
         N = j.g1.n * j.g2.n

@@ -1,4 +1,5 @@
 """CPU-only checks of the boundary and the host plumbing (no GPU compute calls)."""
+import json
 import os
 import re
 import subprocess
@@ -95,6 +96,38 @@ def test_all_pairs_farm_one_vs_k_workers(oracle_build, case, flags, gold):
         assert '"farm_workers": %d' % workers in st
         seen.add(r.stdout)
     assert len(seen) == 1
+
+
+@pytest.mark.parametrize("case,flags,gold", [("c2.fa", ["--fasta", "-t", os.path.join(GOLD, "c2.tree")], None),
+                                             ("c1.fa", ["--fasta", "-t", os.path.join(GOLD, "c1.tree"), "--cs_profile", os.path.join(GOLD, "K50.lib")], "c1.cs.out.fa"),
+                                             ("c1.fa", ["--fasta", "-a"], "c1.a_iter.out.fa")])
+def test_level_and_leaf_farm_one_vs_k_workers(oracle_build, case, flags, gold):
+    """The jobs of a guide-tree level (alignGraphsBatch), the leaves' context profiles and the merges of a level are dealt to
+    the device contexts (farm_shards: by cost, longest first; one host thread per context, host/graph_align.cpp,
+    host/progressive.cpp).  1, 2, 3 and 5 workers over the oracle backend: identical FASTA, identical to the reference's."""
+    exe = os.path.join(oracle_build, "pgmsa_oracle")
+    outs = {}
+    for workers in (1, 2, 3, 5):
+        env = dict(os.environ, PGM_FARM_WORKERS=str(workers))
+        r = subprocess.run([exe] + flags + ["--stats", os.path.join(GOLD, case)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+        assert st["farm_level_workers"] == min(workers, 32 if case == "c2.fa" else 4)
+        if "--cs_profile" in flags:
+            assert st["farm_leaf_workers"] == workers
+        outs[workers] = r.stdout
+    assert len(set(outs.values())) == 1
+    if gold:
+        assert outs[1] == open(os.path.join(GOLD, gold)).read()
+
+
+def test_farm_shards_cover_every_unit_once():
+    """farm_shards is exercised through the driver above; its contract (every unit in exactly one shard, longest first, least
+    loaded worker) is restated here on the Python twin that bench.py uses for the process-per-GPU launch."""
+    from prographmsa_amd import farm
+    for world in (1, 2, 3, 5, 8):
+        sh = farm.lpt_shards([7.0, 7.0, 3.0, 9.0, 1.0, 1.0, 4.0, 12.0, 5.0], world)
+        assert sorted(i for s_ in sh for i in s_) == list(range(9))
 
 
 def test_random_job_generator_is_deterministic():
