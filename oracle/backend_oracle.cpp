@@ -15,6 +15,11 @@ int pgmo_nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t gap_open, in
 int pgmo_csprofile_create(uint32_t K, uint32_t ncols, const double *lprofiles, const double *centre,
                           const double *priors, const int8_t *seq, uint32_t L, double tau, const double *pi,
                           const double *p_uniform, double *out);
+int pgmo_merge_profiles(const pgm_merge_job *job);
+int pgmo_prealigned_counts(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
+                           const uint32_t *pj, int32_t *counts, uint32_t *gaps);
+int pgmo_mldist(const pgm_mldist_model *m, uint32_t npairs, const int32_t *counts, const uint32_t *gaps, const double *seqlen,
+                double *dist, double *var);
 }
 
 namespace pgm {
@@ -33,6 +38,22 @@ struct OracleBackend : Backend {
                         uint32_t *gaps, int) override {
         if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps) != PGM_OK)
             error("error while backtracking");
+    }
+    // f1 / f3 through the oracle's own restatements, so that the golden fixtures (FASTA, --profile_out, newick) pin them too
+    bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs, int) override {
+        for (uint32_t i = 0; i < njobs; ++i)
+            if (pgmo_merge_profiles(&jobs[i]) != PGM_OK) error("pgmo_merge_profiles failed");
+        return true;
+    }
+    bool prealigned_counts_batch(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
+                                 const uint32_t *pj, int32_t *counts, uint32_t *gaps, int) override {
+        if (pgmo_prealigned_counts(dim, nrows, ncols, rows, npairs, pi, pj, counts, gaps) != PGM_OK) error("pgmo_prealigned_counts failed");
+        return true;
+    }
+    bool mldist_batch(const pgm_mldist_model &m, uint32_t npairs, const int32_t *counts, const uint32_t *gaps, const double *seqlen,
+                      double *dist, double *var, int) override {   // (used with PGM_DEVICE_MLDIST=1, as in the product)
+        if (pgmo_mldist(&m, npairs, counts, gaps, seqlen, dist, var) != PGM_OK) error("pgmo_mldist failed");
+        return true;
     }
     void csprofile_create_batch(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                 const double *tau, const double *pi, const double *p_uniform, double *out,

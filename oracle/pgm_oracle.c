@@ -18,6 +18,9 @@
  *                       src/ls_log.h:7-59 (ls_log / ls_log_add, SSE2 variant)
  *   pgmo_nw_pair        src/DistanceFactoryAlign.h:59-127 (alignPair)
  *   pgmo_csprofile_create  src/CSProfile.cpp:175-225 (createProfile)
+ *   pgmo_merge_profiles    src/GraphAlign.h:569-620 (mergeGraphs: node profiles of the merged graph)
+ *   pgmo_prealigned_counts src/DistanceFactoryPrealigned.h:34-90 (pair counts of an alignment)
+ *   pgmo_mldist            src/DistanceFactoryML.h:66-190 (computeDistance / computeMLDist), src/ModelFactory.h:48-67, 104-127
  */
 #include "../include/pgm_hip.h"
 
@@ -618,5 +621,187 @@ int pgmo_csprofile_create(uint32_t K, uint32_t ncols, const double *lprofiles, c
     /* transpose to 20 x (L+2) column-major == [node][20] contiguous: same memory image */
     memcpy(out, profile, sizeof(double) * (size_t)(L + 2) * 20);
     free(profile);
+    return PGM_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* mergeGraphs, node profiles (GraphAlign.h:569-620).  The caller has walked the two mappings (the "unify" loops) and lists
+ * per node of the merged graph its source nodes k1 / k2 (PGM_GAP = none) and whether a g2 node is propagated with model1.P
+ * (the reference does that for SKIPPED g2 nodes, :591).  Per node:
+ *     p = P1 g1[k1]                      (k2 none)
+ *     p = Pb g2[k2]                      (k1 none; Pb = P1 for a skipped node, P2 for a mapped one: :591, :612)
+ *     p = (P1 g1[k1]) .* (P2 g2[k2])     (both: :601)
+ *     node = p.norm() == 0 ? p : p.normalized()
+ * in double.  Association of the matrix-vector product: Eigen 3.0-3.2's column-major gemv as the reference binary shows it
+ * (four columns at a time, res += (c0 v0 + c1 v1) + (c2 v2 + c3 v3), leftover columns one by one); the norm is the
+ * sequential sum of squares, sqrt; normalized() multiplies by the reciprocal (Eigen's scalar quotient for floating
+ * point).  Pinned through the whole-FASTA fixtures (every merged profile enters the next alignGraphs' emission scores). */
+static void pgmo_gemv(const double *P, const double *v, uint32_t n, double *out) {
+    for (uint32_t i = 0; i < n; ++i) out[i] = 0.0;
+    uint32_t j = 0;
+    for (; j + 4 <= n; j += 4) {
+        const double *c0 = P + (size_t)n * j, *c1 = c0 + n, *c2 = c1 + n, *c3 = c2 + n;
+        const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
+        for (uint32_t i = 0; i < n; ++i) out[i] += (c0[i] * v0 + c1[i] * v1) + (c2[i] * v2 + c3[i] * v3);
+    }
+    for (; j < n; ++j) {
+        const double *pc = P + (size_t)n * j;
+        for (uint32_t i = 0; i < n; ++i) out[i] += pc[i] * v[j];
+    }
+}
+
+int pgmo_merge_profiles(const pgm_merge_job *job) {
+    if (!job || !job->sites1 || !job->sites2 || !job->P1 || !job->P2 || !job->k1 || !job->k2 || !job->g2_with_P1 || !job->profiles ||
+        job->dim == 0 || job->dim > 64)
+        return PGM_ERR_INVALID;
+    const uint32_t D = job->dim;
+    double a[64], b[64];
+    for (uint32_t v = 0; v < job->nnodes; ++v) {
+        const uint32_t k1 = job->k1[v], k2 = job->k2[v];
+        if ((k1 == PGM_GAP && k2 == PGM_GAP) || (k1 != PGM_GAP && k1 >= job->n1) || (k2 != PGM_GAP && k2 >= job->n2)) return PGM_ERR_INVALID;
+        double *p = job->profiles + (size_t)D * v;
+        if (k1 != PGM_GAP) pgmo_gemv(job->P1, job->sites1 + (size_t)D * k1, D, a);
+        if (k2 != PGM_GAP) pgmo_gemv(job->g2_with_P1[v] ? job->P1 : job->P2, job->sites2 + (size_t)D * k2, D, b);
+        for (uint32_t i = 0; i < D; ++i) p[i] = (k1 != PGM_GAP && k2 != PGM_GAP) ? a[i] * b[i] : (k1 != PGM_GAP ? a[i] : b[i]);
+        double ss = 0.0;
+        for (uint32_t i = 0; i < D; ++i) ss += p[i] * p[i];
+        const double nrm = sqrt(ss);
+        if (nrm != 0.0) {
+            const double inv = 1.0 / nrm;
+            for (uint32_t i = 0; i < D; ++i) p[i] *= inv;
+        }
+    }
+    return PGM_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* DistanceFactoryPrealigned::computePwDistances, the scan of two aligned rows (DistanceFactoryPrealigned.h:49-79).
+ * rows: nrows x ncols, value() of a residue (0..dim-1), -1 gap, -2 residue without a value.  Only values < 20 are
+ * counted — the reference's literal 20, for every alphabet (:62).  counts(c1, c2) column-major: element c1 + dim c2. */
+int pgmo_prealigned_counts(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
+                           const uint32_t *pj, int32_t *counts, uint32_t *gaps) {
+    if (!rows || !pi || !pj || !counts || !gaps || dim == 0) return PGM_ERR_INVALID;
+    for (uint32_t p = 0; p < npairs; ++p) {
+        if (pi[p] >= nrows || pj[p] >= nrows) return PGM_ERR_INVALID;
+        const int8_t *s1 = rows + (size_t)pi[p] * ncols, *s2 = rows + (size_t)pj[p] * ncols;
+        int32_t *c = counts + (size_t)p * dim * dim;
+        memset(c, 0, sizeof(int32_t) * (size_t)dim * dim);
+        uint32_t g = 0;
+        int gap_opened1 = 0, gap_opened2 = 0;
+        for (uint32_t k = 0; k < ncols; ++k) {
+            const int g1 = s1[k] == -1, g2 = s2[k] == -1;
+            if (!g1 && !g2) {
+                const int c1 = s1[k], c2 = s2[k];
+                if (c1 >= 0 && c1 < 20 && c2 >= 0 && c2 < 20) ++c[(uint32_t)c1 + dim * (uint32_t)c2];
+                gap_opened1 = 0; gap_opened2 = 0;
+            } else if (g1 && g2) {
+                /* skip */
+            } else if (!g1 && !gap_opened1) {
+                ++g; gap_opened1 = 1; gap_opened2 = 0;
+            } else if (!g2 && !gap_opened2) {
+                ++g; gap_opened1 = 0; gap_opened2 = 1;
+            }
+        }
+        gaps[p] = g;
+    }
+    return PGM_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* DistanceFactoryML::computeDistance + computeMLDist (DistanceFactoryML.h:66-190) for the pairs of a batch.  The model is
+ * handed over in the eigen form ModelFactory builds (ModelFactory.h:48-67): getModel(d) = parseDistance (with -m / -M: the
+ * distance itself, NaN -> 5.2, clamped to [min_dist, max_dist], :104-127), P = V diag(exp(sigma d)) V^-1.  Every matrix
+ * product accumulates k = 0..n-1 from zero (one multiply, one add per term), f and f' add the n^2 entries in storage
+ * order: the order of the host mirror (host/distance.cpp, host/model_factory.cpp), whose distances agree with the
+ * reference binary's to the 6 significant digits its newick output prints (tests/golden: nw_pairs.json, *.nw_ml.tree). */
+static void pgmo_matmul(const double *A, const double *B, uint32_t n, double *C) {
+    for (size_t i = 0; i < (size_t)n * n; ++i) C[i] = 0.0;
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t k = 0; k < n; ++k) {
+            const double bk = B[k + n * j];
+            for (uint32_t i = 0; i < n; ++i) C[i + n * j] += A[i + n * k] * bk;
+        }
+}
+static void pgmo_model_P(const pgm_mldist_model *m, double distance, double *P, double *tmp, double *e) {
+    const uint32_t n = m->dim;
+    distance = distance > 0.0 ? distance : 0.0;                 /* std::max(0.0, distance): NaN stays NaN */
+    if (distance != distance) distance = 5.2;
+    double d = distance < m->max_dist ? distance : m->max_dist;  /* std::min(model.distance, max_dist) */
+    d = d > m->min_dist ? d : m->min_dist;                       /* std::max(.., min_dist) */
+    for (uint32_t k = 0; k < n; ++k) e[k] = exp(m->sigma[k] * d);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t k = 0; k < n; ++k) tmp[i + n * k] = m->V[i + n * k] * e[k];
+    pgmo_matmul(tmp, m->Vi, n, P);
+}
+
+int pgmo_mldist(const pgm_mldist_model *m, uint32_t npairs, const int32_t *counts, const uint32_t *gaps, const double *seqlen,
+                double *dist_out, double *var_out) {
+    if (!m || !m->Q || !m->V || !m->Vi || !m->sigma || !counts || !gaps || !seqlen || !dist_out || !var_out || m->dim == 0 || m->dim > 64)
+        return PGM_ERR_INVALID;
+    const uint32_t n = m->dim, nn = n * n;
+    double *P = (double *)malloc(sizeof(double) * nn * 4 + sizeof(double) * n);
+    if (!P) return PGM_ERR_NOMEM;
+    double *pp = P + nn, *ppp = pp + nn, *tmp = ppp + nn, *e = tmp + nn;
+    const double EPSILON = 1e-5;
+    const uint32_t MAXITER = 20;
+    for (uint32_t pr = 0; pr < npairs; ++pr) {
+        const int32_t *c = counts + (size_t)pr * nn;
+        double ident = 0, total = 0;
+        for (uint32_t i = 0; i < n; ++i) ident += c[i + n * i];
+        for (uint32_t i = 0; i < nn; ++i) total += c[i];
+        double dist0 = 1.0 - ident / total, dist, var;
+        if (m->mldist || m->mldist_gap) {
+            if (total == 0 || dist0 > 0.85) { dist = dist0 = m->dist_max; var = m->var_max; }
+            else { dist = dist0 = -log(1.0 - dist0 - 0.2 * dist0 * dist0); var = dist / total; }
+            if (total > 0 && ident != total) {
+                /* computeMLDist (:66-135) */
+                const double d00 = dist, v00 = var;
+                double dist_min = 0, dist_max = INFINITY, delta = 1;
+                uint32_t iteration = 0;
+                while (fabs(delta) > EPSILON) {
+                    if (iteration > MAXITER) {
+                        if (dist_max == INFINITY) { dist = m->dist_max; var = m->var_max; }
+                        else { dist = d00; var = v00; }
+                        break;
+                    }
+                    pgmo_model_P(m, dist, P, tmp, e);
+                    pgmo_matmul(m->Q, P, n, pp);
+                    pgmo_matmul(m->Q, pp, n, ppp);
+                    double f = 0, ff = 0;
+                    for (uint32_t i = 0; i < nn; ++i) {
+                        const double ci = c[i];
+                        f += ci * pp[i] / P[i];
+                        ff += (ci * (ppp[i] * P[i] - pp[i] * pp[i])) / (P[i] * P[i]);
+                    }
+                    if (m->mldist_gap) {
+                        const double grate = m->indel_rate * seqlen[pr] * dist;
+                        f += (-grate + gaps[pr]) / dist;
+                        ff += -(double)gaps[pr] / (dist * dist);
+                    }
+                    var = -1.0 / ff;
+                    if (f > 0) dist_min = dist_min > dist ? dist_min : dist;
+                    else dist_max = dist_max < dist ? dist_max : dist;
+                    double new_dist = dist - f / ff;
+                    if (!(new_dist < dist_max && new_dist > dist_min)) {
+                        const double upper = (dist_max == INFINITY) ? dist * 3 : dist_max;
+                        new_dist = (upper + dist_min) / 2.0;
+                    }
+                    delta = 1.0 - new_dist / dist;
+                    dist = new_dist;
+                    ++iteration;
+                }
+            }
+        } else {
+            if (total == 0) { dist = dist0 = 1.0; var = m->var_max; }
+            else { dist = dist0; var = dist0 / total; }
+        }
+        if (!(dist < m->dist_max)) { dist = m->dist_max; var = m->var_max; }
+        if (dist > m->cutoff_dist) dist = m->cutoff_dist;
+        if (var < m->var_min) var = m->var_min;
+        if (!(var < m->var_max)) var = m->var_max;
+        dist_out[pr] = dist;
+        var_out[pr] = var;
+    }
+    free(P);
     return PGM_OK;
 }

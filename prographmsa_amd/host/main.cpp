@@ -46,6 +46,19 @@ struct BackendStartup {
 } g_startup;
 }  // namespace
 
+static std::string value_name(const Alphabet &a, int j) {   // ALPHABET(j).asString()
+    static const char *aa = "ACDEFGHIKLMNPQRSTVWY";
+    if (a.kind == ALPHA_AA) return std::string(1, aa[j]);
+    static const char nt[] = "TCAG";
+    int k = -1;
+    for (int c = 0; c < 64; ++c) {
+        const std::string cod = {nt[c >> 4], nt[(c >> 2) & 3], nt[c & 3]};
+        if (cod == "TAA" || cod == "TAG" || cod == "TGA") continue;
+        if (++k == j) return cod;
+    }
+    return "?";
+}
+
 static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &seqs,
                    std::map<std::string, std::string> &out_aligned, PhyTree *&out_tree, bool stats) {
     // strip start/stop (main.cpp:332-353)
@@ -110,7 +123,18 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         sequence_t aseq = kv.second;
         if (any_start) aseq.insert(aseq.begin(), startStripped[kv.first] ? a.unknown() : a.gap());
         if (any_end) aseq.insert(aseq.end(), endStripped[kv.first] ? a.unknown() : a.gap());
-        out_aligned[kv.first] = stringFromSequence(a, aseq, seqs.at(kv.first));
+        out_aligned[kv.first] = seqs.count(kv.first) ? stringFromSequence(a, aseq, seqs.at(kv.first)) : stringFromSequence(a, aseq);   // (ancestral rows have no original)
+    }
+    if (!cmdlineopts.profile_file.empty()) {   // write_profile (profile.h:12-31; main.cpp:451-456): default stream formatting, 6 significant digits
+        std::ofstream pf(cmdlineopts.profile_file.c_str());
+        for (const auto &kv : result.profiles) {
+            pf << '>' << kv.first << std::endl;
+            for (int j = 0; j < a.DIM; ++j) {
+                pf << value_name(a, j);
+                for (index_t k = 0; k < kv.second.cols; ++k) pf << '\t' << kv.second.data[(size_t)j + (size_t)a.DIM * k];
+                pf << std::endl;
+            }
+        }
     }
     if (stats) {
         Backend &be = default_backend();
@@ -161,6 +185,8 @@ int main(int argc, char **argv) {
             else if (s == "-D" || s == "--max_dist") { cmdlineopts.max_dist = atof(val().c_str()); maxdist_set = true; }
             else if (s == "-p" || s == "--min_pdist") cmdlineopts.min_pdist = atof(val().c_str());
             else if (s == "-P" || s == "--max_pdist") cmdlineopts.max_pdist = atof(val().c_str());
+            else if (s == "--ancestral_seqs") cmdlineopts.ancestral_flag = true;
+            else if (s == "--profile_out") cmdlineopts.profile_file = val();
             else if (s == "--dump_jobs") dump = val();
             else if (s == "--dump_dist") dist_dump = val();
             else if (s == "--stats") stats = true;

@@ -38,6 +38,7 @@ struct cmdlineopts_t {
     bool fasta_flag = false, noforcealign_flag = false, nwdist_flag = false, onlytree_flag = false;
     bool mldist_flag = false, mldist_gap_flag = false, codon_flag = false, inputorder_flag = false;
     bool ancestral_flag = false;
+    std::string profile_file;   // --profile_out (main.cpp:132)
     double indel_rate = 0.0093359375;
     double end_indel_prob = 0.12;
     double gapext_prob = 0.6119140625;
@@ -328,8 +329,10 @@ private:
 
 // ---------------------------------------------------------------------------------------
 // ProgressiveAlignment.{h,cpp}
+struct Profile { int dim = 0; index_t cols = 0; std::vector<double> data; };   // Model<A>::Profile: dim x cols, column-major
 struct ProgressiveAlignmentResult {   // ProgressiveAlignment.h:27-37
     std::map<std::string, sequence_t> aligned_sequences;
+    std::map<std::string, Profile> profiles;   // leaves always; ancestors with --ancestral_seqs (:73, :362, :410)
     Graph graph;
     score_t score = 0;
     index_t n_tr_indels = 0;

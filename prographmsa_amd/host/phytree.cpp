@@ -138,7 +138,30 @@ static void get_tree_order_rec(const PhyTree *tree, std::vector<std::string> &or
     else
         for (index_t i = 0; i < tree->n_children(); ++i) get_tree_order_rec(&(*tree)[i], order);
 }
+// (--ancestral_seqs: every internal node's name, the sorted list of its leaves in parentheses, stands between the orders of
+//  its two subtrees: PhyTree.cpp:118-160)
+static std::string list_to_name(const std::vector<std::string> &leaves) {
+    std::vector<std::string> sorted = leaves;
+    std::sort(sorted.begin(), sorted.end());
+    std::string s = "(";
+    bool first = true;
+    for (const std::string &name : sorted)
+        if (name[0] != '(') { if (!first) s += ","; first = false; s += name; }
+    return s + ")";
+}
+static std::vector<std::string> get_tree_order_ancestral(const PhyTree *tree) {
+    std::vector<std::string> order;
+    if (tree->isLeaf()) { order.push_back(tree->getName()); return order; }
+    for (index_t i = 0; i < tree->n_children(); ++i) {
+        const std::vector<std::string> sub = get_tree_order_ancestral(&(*tree)[i]);
+        const size_t pos = order.size();
+        order.insert(order.end(), sub.begin(), sub.end());
+        if (i != 0) order.insert(order.begin() + pos, list_to_name(order));
+    }
+    return order;
+}
 std::vector<std::string> get_tree_order(const PhyTree *tree) {
+    if (cmdlineopts.ancestral_flag) return get_tree_order_ancestral(tree);
     std::vector<std::string> order;
     get_tree_order_rec(tree, order);
     return order;

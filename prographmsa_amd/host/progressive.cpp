@@ -40,6 +40,53 @@ static void extend_alignment(const Alphabet &a, ProgressiveAlignmentResult &resu
     else for (size_t r = 0; r < rows.size(); ++r) fill(r);
 }
 
+// ancestral sequences and profiles (--ancestral_seqs; ProgressiveAlignment.h:289-411)
+static std::string create_ancestral_seq_name(const std::map<std::string, sequence_t> &aligned_seqs) {
+    std::vector<std::string> leaves;
+    for (const auto &kv : aligned_seqs) if (kv.first[0] != '(') leaves.push_back(kv.first);
+    std::sort(leaves.begin(), leaves.end());
+    std::string s = "(";
+    for (size_t i = 0; i < leaves.size(); ++i) { if (i) s += ","; s += leaves[i]; }
+    return s + ")";
+}
+static int8_t symbol_of(const Alphabet &a, int j) {   // ALPHABET(j): the symbol whose value() is j
+    static const char *aa = "ACDEFGHIKLMNPQRSTVWY";
+    if (a.kind == ALPHA_AA) return sequenceFromString(a, std::string(1, aa[j]))[0];
+    static const char nt[] = "TCAG";   // the 61 sense codons in TCAG order (Alphabet.cpp)
+    int k = -1;
+    for (int c = 0; c < 64; ++c) {
+        const std::string cod = {nt[c >> 4], nt[(c >> 2) & 3], nt[c & 3]};
+        if (cod == "TAA" || cod == "TAG" || cod == "TGA") continue;
+        if (++k == j) return sequenceFromString(a, cod)[0];
+    }
+    return a.unknown();
+}
+// the sequence and the profile of `src`'s nodes as seen from the (new) graph of `result`: node i of the result shows column
+// (col .* pi) of source node mapping[i] if it is a matched node, a gap otherwise.  prelim: src = result.graph itself.
+static void ancestral_seq(const Alphabet &a, ProgressiveAlignmentResult &result, const std::string &anc_name, const Graph &src, const std::vector<index_t> *mapping,
+                          const std::vector<bool> &matched, const Model &model) {
+    const index_t n = result.graph.size();
+    const int D = a.DIM;
+    sequence_t extended(n - 2, a.unknown());
+    Profile prof;
+    prof.dim = D;
+    std::vector<double> col((size_t)D);
+    for (index_t i = 1; i < n - 1; ++i) {
+        const bool on = matched[i] && (!mapping || (*mapping)[i] != (index_t)-1);
+        if (!on) { extended[i - 1] = a.gap(); continue; }
+        const double *g = src.col(mapping ? (*mapping)[i] : i);
+        int best = 0;
+        double sum = 0;
+        for (int k = 0; k < D; ++k) { col[(size_t)k] = g[k] * model.pi[(size_t)k]; if (col[(size_t)k] > col[(size_t)best]) best = k; }   // maxCoeff: the first maximum
+        extended[i - 1] = symbol_of(a, best);
+        for (int k = 0; k < D; ++k) sum += col[(size_t)k];
+        for (int k = 0; k < D; ++k) prof.data.push_back(col[(size_t)k] / sum);
+        ++prof.cols;
+    }
+    result.aligned_sequences[anc_name] = extended;
+    result.profiles[anc_name] = std::move(prof);
+}
+
 void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
     static unsigned nt = []() {
         unsigned v = std::thread::hardware_concurrency();
@@ -101,7 +148,14 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         nd.res.score = 0;
         nd.res.n_tr_indels = 0;
         nd.res.is_csprofile = false;
-        if (!csprofile) nd.res.graph = SequenceGraph(a, it->second);
+        if (!csprofile) {
+            nd.res.graph = SequenceGraph(a, it->second);
+            if (!cmdlineopts.profile_file.empty()) {   // result.profiles[name] = sites without START / END (ProgressiveAlignment.h:73)
+                Profile &pf = nd.res.profiles[it->first];
+                pf.dim = a.DIM; pf.cols = nd.res.graph.size() - 2;
+                pf.data.assign(nd.res.graph.col(1), nd.res.graph.col(1) + (size_t)a.DIM * pf.cols);
+            }
+        }
     });
     if (csprofile) {
         // SequenceGraph(seq, csprofile, model_factory.getModel(branch_length)) for every leaf in one
@@ -261,6 +315,15 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             result.graph = anc.graph;
             extend_alignment(a, result, anc.mapping1, r1.aligned_sequences, L == 1);
             extend_alignment(a, result, anc.mapping2, r2.aligned_sequences, L == 1);
+            if (!cmdlineopts.profile_file.empty() || cmdlineopts.ancestral_flag) {
+                result.profiles.insert(r1.profiles.begin(), r1.profiles.end());
+                result.profiles.insert(r2.profiles.begin(), r2.profiles.end());
+            }
+            if (cmdlineopts.ancestral_flag) {   // ProgressiveAlignment.h:458-466
+                if (r1.aligned_sequences.size() > 1) ancestral_seq(a, result, create_ancestral_seq_name(r1.aligned_sequences), r1.graph, &anc.mapping1, anc.is_matched, p.model1);
+                if (r2.aligned_sequences.size() > 1) ancestral_seq(a, result, create_ancestral_seq_name(r2.aligned_sequences), r2.graph, &anc.mapping2, anc.is_matched, p.model2);
+                ancestral_seq(a, result, create_ancestral_seq_name(result.aligned_sequences), result.graph, nullptr, anc.is_matched, p.model);
+            }
             // children are no longer needed (the reference copies them by value and drops them)
             r1 = ProgressiveAlignmentResult();
             r2 = ProgressiveAlignmentResult();

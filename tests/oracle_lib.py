@@ -83,3 +83,44 @@ def csprofile_create(K, ncols, lprofiles, centre, priors, seq, tau, pi, p_unifor
                                   _p(arrs[3], C.c_double), _p(arrs[4], C.c_double), _p(out, C.c_double))
     assert rc == 0
     return out
+
+
+# ---- f1 / f3: node profiles of a merge, pair counts of an alignment, ML distances -----------------------------------------
+from prographmsa_amd import pgm_merge_job, pgm_mldist_model  # noqa: E402
+
+_l.pgmo_merge_profiles.restype = C.c_int
+_l.pgmo_merge_profiles.argtypes = [C.POINTER(pgm_merge_job)]
+_l.pgmo_prealigned_counts.restype = C.c_int
+_l.pgmo_prealigned_counts.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int8), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+_l.pgmo_mldist.restype = C.c_int
+_l.pgmo_mldist.argtypes = [C.POINTER(pgm_mldist_model), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                           C.POINTER(C.c_double)]
+
+
+def merge_profiles(job):
+    """Oracle node profiles of one pgm_merge_job (writes job.profiles); returns the status."""
+    return _l.pgmo_merge_profiles(C.byref(job))
+
+
+def prealigned_counts(dim, rows, pi, pj):
+    """rows: (nrows, ncols) int8.  Returns (counts [npairs * dim * dim] int32, gaps [npairs] uint32)."""
+    rows = np.ascontiguousarray(rows, np.int8)
+    pi = np.ascontiguousarray(pi, np.uint32); pj = np.ascontiguousarray(pj, np.uint32)
+    counts = np.zeros(len(pi) * dim * dim, np.int32); gaps = np.zeros(len(pi), np.uint32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = _l.pgmo_prealigned_counts(dim, rows.shape[0], rows.shape[1], P(rows, C.c_int8), len(pi), P(pi, C.c_uint32), P(pj, C.c_uint32),
+                                   P(counts, C.c_int32), P(gaps, C.c_uint32))
+    assert rc == 0
+    return counts, gaps
+
+
+def mldist(model, counts, gaps, seqlen):
+    """model: pgm_mldist_model.  Returns (dist, var) float64 arrays."""
+    counts = np.ascontiguousarray(counts, np.int32); gaps = np.ascontiguousarray(gaps, np.uint32); seqlen = np.ascontiguousarray(seqlen, np.float64)
+    n = len(gaps)
+    dist = np.zeros(n); var = np.zeros(n)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = _l.pgmo_mldist(C.byref(model), n, P(counts, C.c_int32), P(gaps, C.c_uint32), P(seqlen, C.c_double), P(dist, C.c_double), P(var, C.c_double))
+    assert rc == 0
+    return dist, var

@@ -1,7 +1,7 @@
 """GPU parity of the guide-tree tail: batched ML distances and the pair counts of an alignment.
 
-pgm_prealigned_counts_batch is integer work: bit-exact against a plain restatement of the reference's column scan
-(src/DistanceFactoryPrealigned.h:34-90).  pgm_mldist_batch keeps the host estimator's operation order (host/distance.cpp,
+pgm_prealigned_counts_batch is integer work: bit-exact against the oracle's pgmo_prealigned_counts
+(src/DistanceFactoryPrealigned.h:34-90).  pgm_mldist_batch against the oracle's pgmo_mldist on synthetic reversible models.  pgm_mldist_batch keeps the host estimator's operation order (host/distance.cpp,
 the mirror of src/DistanceFactoryML.h:66-190) but uses the device library's exp / log: tolerance 1e-12 relative, checked
 through the product driver (`pgmsa --dump_dist`, host estimator vs PGM_DEVICE_MLDIST=1) on the committed families."""
 import ctypes as C
@@ -18,22 +18,11 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _scan(r1, r2, D):
-    """The reference's loop over the columns of two aligned rows (values: residue 0..D-1, -1 gap, -2 residue without value)."""
-    counts = np.zeros((D, D), np.int32)
-    gaps, open1, open2 = 0, False, False
-    for c1, c2 in zip(r1, r2):
-        g1, g2 = c1 == -1, c2 == -1
-        if not g1 and not g2:
-            if 0 <= c1 < 20 and 0 <= c2 < 20:
-                counts[c2, c1] += 1          # counts(c1, c2), column-major: element c1 + D * c2
-            open1 = open2 = False
-        elif g1 and g2:
-            pass
-        elif not g1 and not open1:
-            gaps += 1; open1, open2 = True, False
-        elif not g2 and not open2:
-            gaps += 1; open1, open2 = False, True
-    return counts.reshape(-1), gaps
+    """The reference's loop over the columns of two aligned rows: the oracle's pgmo_prealigned_counts (oracle/pgm_oracle.c,
+    src/DistanceFactoryPrealigned.h:49-79) on one pair."""
+    import oracle_lib
+    c, g = oracle_lib.prealigned_counts(D, np.array([r1, r2], np.int8), [0], [1])
+    return c, int(g[0])
 
 
 @pytest.mark.parametrize("D,nrows,L", [(20, 7, 1), (20, 9, 63), (20, 12, 64), (20, 10, 65), (20, 8, 1000), (61, 6, 333), (20, 40, 3274)])
@@ -128,3 +117,55 @@ def test_c3_prealigned_counts_at_full_size(ctx, tmp_path):
     for k in rng.integers(0, len(pairs), 60):
         rc, rg = _scan(rows[pairs[k][0]].tolist(), rows[pairs[k][1]].tolist(), 20)
         assert np.array_equal(counts[k * 400:(k + 1) * 400], rc) and gaps[k] == rg
+
+
+@pytest.mark.parametrize("flags", [(1, 0), (0, 1), (0, 0)])
+def test_mldist_kernel_against_the_oracle(ctx, flags):
+    """pgm_mldist_batch vs oracle/pgm_oracle.c pgmo_mldist (DistanceFactoryML.h:66-190) on a random reversible 20-state model in
+    eigen form and pair counts drawn from P(d) at distances 0.02 .. 3 (incl. identical pairs, empty pairs, saturated pairs):
+    1e-12 relative (device exp / log differ from glibc's in the last bit); the p-distance branch (no -m / -M) bit for bit."""
+    import oracle_lib
+    import prographmsa_amd as pg
+    rng = np.random.default_rng(77)
+    D = 20
+    pi = rng.dirichlet(np.ones(D) * 5)
+    S = rng.gamma(0.5, 1.0, (D, D)); S = (S + S.T) / 2; np.fill_diagonal(S, 0)
+    Q = S * pi[None, :]
+    np.fill_diagonal(Q, -Q.sum(1))
+    Q /= -(pi * np.diag(Q)).sum()
+    sig, V = np.linalg.eig(Q)
+    sig, V = sig.real, V.real
+    Vi = np.linalg.inv(V)
+    npairs = 300
+    counts = np.zeros((npairs, D, D), np.int32)
+    gaps = rng.integers(0, 30, npairs).astype(np.uint32)
+    seqlen = rng.uniform(50, 1200, npairs)
+    for p in range(npairs):
+        d = float(rng.choice([0.02, 0.1, 0.3, 0.8, 1.5, 3.0]))
+        Pd = (V * np.exp(sig * d)[None, :]) @ Vi
+        n = int(rng.integers(0, 900))
+        if p % 17 == 0:
+            n = 0                                   # empty pair
+        a = rng.choice(D, n, p=pi)
+        if p % 13 == 0:
+            b = a.copy()                            # identical sequences
+        else:
+            b = np.array([rng.choice(D, p=np.clip(Pd[x], 0, None) / np.clip(Pd[x], 0, None).sum()) for x in a], int) if n else a
+        for x, y in zip(a, b):
+            counts[p, y, x] += 1                    # counts(c1, c2) column-major
+    m = pg.pgm_mldist_model()
+    keep = [np.asfortranarray(Q), np.asfortranarray(V), np.asfortranarray(Vi), np.ascontiguousarray(sig)]
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    m.dim = D
+    m.Q, m.V, m.Vi, m.sigma = P(keep[0], C.c_double), P(keep[1], C.c_double), P(keep[2], C.c_double), P(keep[3], C.c_double)
+    m.dist_max, m.var_max, m.var_min, m.cutoff_dist, m.min_dist, m.max_dist, m.indel_rate = 2.2, 1e3, 1e-5, 2.2, 0.05, 2.2, 0.0093359375
+    m.mldist, m.mldist_gap = flags
+    cflat = np.ascontiguousarray(counts.reshape(-1))
+    dist = np.zeros(npairs); var = np.zeros(npairs)
+    pg.check(pg.lib.pgm_mldist_batch(ctx.handle, C.byref(m), npairs, P(cflat, C.c_int32), P(gaps, C.c_uint32), P(seqlen, C.c_double), P(dist, C.c_double), P(var, C.c_double)))
+    rd, rv = oracle_lib.mldist(m, cflat, gaps, seqlen)
+    if flags == (0, 0):
+        assert np.array_equal(dist.view(np.uint64), rd.view(np.uint64)) and np.array_equal(var.view(np.uint64), rv.view(np.uint64))
+    else:
+        assert np.max(np.abs(dist - rd) / np.maximum(np.abs(rd), 1e-300)) <= 1e-12
+        assert np.max(np.abs(var - rv) / np.maximum(np.abs(rv), 1e-300)) <= 1e-9   # (the variance is -1 / f'' of the last Newton step: a difference of two large sums)

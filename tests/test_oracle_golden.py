@@ -42,13 +42,34 @@ def test_pairwise_alignments_identical(oracle_build, tmp_path):
     assert not bad, bad
 
 
-def test_nw_distance_pairs(oracle_build, tmp_path):
-    """alignPair + computeDistance: 2-sequence `-a [-m] -T -i 0` prints (b:d/2,a:d/2); at 6 s.f."""
+@pytest.mark.parametrize("batched", [False, True])
+def test_nw_distance_pairs(oracle_build, tmp_path, batched, monkeypatch):
+    """alignPair + computeDistance: 2-sequence `-a [-m] -T -i 0` prints (b:d/2,a:d/2); at 6 s.f.  batched: the distances come
+    from the oracle's pgmo_mldist (oracle/pgm_oracle.c, the checker of the device kernel pgm_mldist_kernel) instead of the
+    host mirror's estimator — both follow src/DistanceFactoryML.h:66-190."""
+    if batched:
+        monkeypatch.setenv("PGM_DEVICE_MLDIST", "1")
     nw = json.load(open(os.path.join(GOLD, "nw_pairs.json")))
     for seed, p in nw.items():
         (tmp_path / "p.fa").write_text(p["fasta"])
         assert run_oracle(oracle_build, ["-a", "-m", "-T", "-i", "0", str(tmp_path / "p.fa")]) == p["ml"], seed
         assert run_oracle(oracle_build, ["-a", "-T", "-i", "0", str(tmp_path / "p.fa")]) == p["pdist"], seed
+
+
+def test_ancestral_sequences_and_profiles(oracle_build, tmp_path):
+    """Merge numerics (mergeGraphs' node profiles, GraphAlign.h:569-620 = pgmo_merge_profiles through the oracle backend):
+    --ancestral_seqs --profile_out prints every ancestor's profile at 6 significant digits and adds the ancestral rows to the
+    FASTA (ProgressiveAlignment.h:289-411, profile.h).  3 x 30 family in full text, 8 x 120 / 64 x 400 / 6 x 60 codons by md5."""
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    prof = str(tmp_path / "p.prof")
+    out = run_oracle(oracle_build, ["--fasta", "--ancestral_seqs", "--profile_out", prof, "-t", os.path.join(GOLD, "a1.tree"), os.path.join(GOLD, "a1.fa")])
+    assert out == gold("a1.anc.out.fa")
+    assert open(prof).read() == gold("a1.anc.prof")
+    for name, flags in (("c1", []), ("c2", []), ("cd1", ["--codon"])):
+        out = run_oracle(oracle_build, flags + ["--fasta", "--ancestral_seqs", "--profile_out", prof, "-t", os.path.join(GOLD, name + ".tree"), os.path.join(GOLD, name + ".fa")])
+        assert hashlib.md5(out.encode()).hexdigest() == md5[name + ".anc.out.fa"], name
+        if name + ".anc.prof" in md5:   # (amino acids; the codon profiles are not reproducible to 6 digits: ECM expm vs Eigen's EigenSolver)
+            assert hashlib.md5(open(prof, "rb").read()).hexdigest() == md5[name + ".anc.prof"], name
 
 
 @pytest.mark.parametrize("case,flags", [
