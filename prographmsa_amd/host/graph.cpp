@@ -96,6 +96,30 @@ void Graph::setRepeatsFromMap(const RepeatMap &rep_map) {
     for (index_t i = 0; i < n_; ++i) r_rowptr_[i + 1] += r_rowptr_[i];
 }
 
+void Graph::addRepeats(const std::vector<std::vector<int>> &tr_homologies) {
+    RepeatMap tredges;
+    for (const std::vector<int> &h : tr_homologies) {   // getRepeatEdges (Graph.h:48-79), offset 0
+        for (index_t from = 0; from != h.size(); ++from) {
+            if (h[from] < 0) continue;
+            index_t n_units = 0;
+            bool take_next = false;
+            for (index_t to = from + 1; to != h.size(); ++to) {
+                if (h[to] < 0) continue;
+                if (h[to] <= h[to - 1]) n_units += 1;
+                if (take_next) {
+                    const std::pair<index_t, index_t> key(to, from);
+                    auto it = tredges.find(key);
+                    if (it != tredges.end()) it->second = std::min(it->second, n_units);
+                    else tredges[key] = n_units;
+                    take_next = false;
+                }
+                if (h[to] == h[from]) take_next = true;
+            }
+        }
+    }
+    setRepeatsFromMap(tredges);
+}
+
 pgm_graph Graph::flat() const {
     pgm_graph g;
     g.n = n_;

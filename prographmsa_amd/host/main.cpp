@@ -88,6 +88,8 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
     if (getenv("PGM_HOST_PROFILE"))
         fprintf(stderr, "backend start-up %.1f ms, of which %.1f ms waited for after the set-up\n", t_init * 1e3,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    std::map<std::string, std::vector<repeat_t>> reps;   // main.cpp:367-370 (detection by T-REKS itself is not built here: --read_repeats only)
+    if (!cmdlineopts.readreps_file.empty()) reps = read_repeats(a, cmdlineopts.readreps_file, seqs2);
     PhyTree *tree = nullptr;
     t0 = std::chrono::steady_clock::now();
     if (!cmdlineopts.tree_file.empty()) {
@@ -103,7 +105,7 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
     // further rounds of alignment followed by estimation of an improved tree from the induced pairwise distances
     // (main.cpp:404-430; the default is two such rounds when no tree is given)
     for (int i = 0; i < cmdlineopts.iters; ++i) {
-        result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
+        result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory, &reps);
         for (auto it = result.aligned_sequences.begin(); it != result.aligned_sequences.end();)   // ancestral sequences
             if (!it->first.empty() && it->first[0] == '(') it = result.aligned_sequences.erase(it); else ++it;
         if (i > 0 && result.aligned_sequences == old_result.aligned_sequences) break;   // converged
@@ -113,7 +115,7 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "guide tree from the alignment: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count());
         old_result = result;
     }
-    if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory);
+    if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory, &reps);
     if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "[%.1f ms] back in main\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     double t_prog = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     out_tree = tree;
@@ -124,6 +126,10 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         if (any_start) aseq.insert(aseq.begin(), startStripped[kv.first] ? a.unknown() : a.gap());
         if (any_end) aseq.insert(aseq.end(), endStripped[kv.first] ? a.unknown() : a.gap());
         out_aligned[kv.first] = seqs.count(kv.first) ? stringFromSequence(a, aseq, seqs.at(kv.first)) : stringFromSequence(a, aseq);   // (ancestral rows have no original)
+    }
+    if (cmdlineopts.repeats_flag) {
+        if (cmdlineopts.readreps_file.empty()) error("-R: tandem-repeat detection (T-REKS, a Java program) is not built here; supply the repeats with --read_repeats");
+        std::cerr << "TR indels: " << result.n_tr_indels << std::endl;   // main.cpp:447-449
     }
     if (!cmdlineopts.profile_file.empty()) {   // write_profile (profile.h:12-31; main.cpp:451-456): default stream formatting, 6 significant digits
         std::ofstream pf(cmdlineopts.profile_file.c_str());
@@ -187,6 +193,8 @@ int main(int argc, char **argv) {
             else if (s == "-P" || s == "--max_pdist") cmdlineopts.max_pdist = atof(val().c_str());
             else if (s == "--ancestral_seqs") cmdlineopts.ancestral_flag = true;
             else if (s == "--profile_out") cmdlineopts.profile_file = val();
+            else if (s == "--read_repeats") cmdlineopts.readreps_file = val();
+            else if (s == "-R" || s == "--repeats") cmdlineopts.repeats_flag = true;
             else if (s == "--dump_jobs") dump = val();
             else if (s == "--dump_dist") dist_dump = val();
             else if (s == "--stats") stats = true;

@@ -39,6 +39,8 @@ struct cmdlineopts_t {
     bool mldist_flag = false, mldist_gap_flag = false, codon_flag = false, inputorder_flag = false;
     bool ancestral_flag = false;
     std::string profile_file;   // --profile_out (main.cpp:132)
+    std::string readreps_file;  // --read_repeats (main.cpp:108)
+    bool repeats_flag = false;  // -R: here only the "TR indels" lines on stderr (T-REKS itself is not run: --read_repeats supplies the repeats)
     double indel_rate = 0.0093359375;
     double end_indel_prob = 0.12;
     double gapext_prob = 0.6119140625;
@@ -168,6 +170,11 @@ protected:
     void fillInitialEdges();                            // :35-46
     void setEdgesFromMap(const EdgeMap &edge_map);      // :81-90
     void setRepeatsFromMap(const RepeatMap &rep_map);   // :92-100
+public:
+    // tandem-repeat edges from the unit homologies of the graph's nodes (Graph.h:48-79, 458-469): tr_homology[i] = column of
+    // node i + 1 inside its repeat unit, -1 outside a repeat; replaces the repeat matrix
+    void addRepeats(const std::vector<std::vector<int>> &tr_homologies);
+private:
     int dim_;
     index_t n_;
     std::vector<double> sites_;  // dim x n column-major
@@ -330,9 +337,14 @@ private:
 // ---------------------------------------------------------------------------------------
 // ProgressiveAlignment.{h,cpp}
 struct Profile { int dim = 0; index_t cols = 0; std::vector<double> data; };   // Model<A>::Profile: dim x cols, column-major
+struct repeat_t { index_t len = 0, start = 0; std::vector<int> tr_hom; };        // Repeat.h
+// --read_repeats: T-REKS output (RepeatDetectionTReks.cpp:62-157) against the (start / stop stripped) sequences
+std::map<std::string, std::vector<repeat_t>> read_repeats(const Alphabet &a, const std::string &filename, const std::map<std::string, sequence_t> &seqs);
 struct ProgressiveAlignmentResult {   // ProgressiveAlignment.h:27-37
     std::map<std::string, sequence_t> aligned_sequences;
     std::map<std::string, Profile> profiles;   // leaves always; ancestors with --ancestral_seqs (:73, :362, :410)
+    std::vector<std::vector<int>> tr_homologies;   // per annotated repeat: unit column of every node of the graph (without START / END), -1 elsewhere
+    std::vector<std::string> tr_source;
     Graph graph;
     score_t score = 0;
     index_t n_tr_indels = 0;
@@ -346,7 +358,8 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn);
 // recursion; internal nodes whose children are finished are aligned together in one batch.
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
                                                  const PhyTree &tree, const CSProfile *csprofile,
-                                                 const ModelFactory &model_factory);
+                                                 const ModelFactory &model_factory,
+                                                 const std::map<std::string, std::vector<repeat_t>> *repeats = nullptr);
 
 // ---------------------------------------------------------------------------------------
 // Distances / guide tree

@@ -12,7 +12,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <functional>
+#include <iostream>
+#include <sstream>
 #include <thread>
 
 namespace pgm {
@@ -100,6 +103,7 @@ void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
 
 namespace {
 struct Node {
+    std::string tr_note;   // -R: "TR indels at (...): n" of this internal node
     const PhyTree *tree;
     int child[2] = {-1, -1};
     int height = 0;
@@ -127,9 +131,76 @@ static int collect(const PhyTree &t, std::vector<Node> &nodes) {
     return (int)nodes.size() - 1;
 }
 
+// extend_tr_homologies (ProgressiveAlignment.h:266-287)
+static void extend_tr_homologies(ProgressiveAlignmentResult &result, const std::vector<index_t> &mapping, const std::vector<std::vector<int>> &tr_homologies,
+                                 const std::vector<std::string> &tr_source) {
+    const index_t n = result.graph.size();
+    for (size_t r = 0; r < tr_homologies.size(); ++r) {
+        std::vector<int> extended(n - 2, -1);
+        const std::vector<int> &original = tr_homologies[r];
+        index_t k = 0;
+        for (index_t j = 1; j < n - 1; ++j) extended[j - 1] = mapping[j] != (index_t)-1 ? original[k++] : -1;
+        result.tr_homologies.push_back(extended);
+        result.tr_source.push_back(tr_source[r]);
+    }
+}
+
+// --read_repeats: the T-REKS report (RepeatDetectionTReks.cpp:62-151).  Per sequence ('>' line) any number of repeats: a header
+// line "Length: ... from S to E ..." (S 1-based), then the aligned repeat units, one per line, up to a line of asterisks; '-',
+// blanks and tabs are gaps; the residues of the units must spell the sequence from position S on.
+static std::string strip_ws(const std::string &s) {
+    size_t b = 0, e = s.size();
+    while (b < e && isspace((unsigned char)s[b])) ++b;
+    while (e > b && isspace((unsigned char)s[e - 1])) --e;
+    return s.substr(b, e - b);
+}
+std::map<std::string, std::vector<repeat_t>> read_repeats(const Alphabet &a, const std::string &filename, const std::map<std::string, sequence_t> &seqs) {
+    std::map<std::string, std::string> seqs2;
+    for (const auto &kv : seqs) seqs2[kv.first] = stringFromSequence(a, kv.second);
+    std::ifstream in(filename.c_str());
+    std::map<std::string, std::vector<repeat_t>> map;
+    index_t n_sequences = 0, n_repeats = 0;
+    std::string name, line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '>') { name = strip_ws(line.substr(1)); ++n_sequences; }
+        else if (line.compare(0, 7, "Length:") == 0) {
+            const size_t from = line.find("from");
+            if (from == line.npos) throw pgm_exception("format error (from)");
+            const size_t to = line.find("to", from);
+            if (to == line.npos) throw pgm_exception("format error (to)");
+            repeat_t repeat;
+            ++n_repeats;
+            long start = 0;
+            { std::stringstream ss; ss << line.substr(from + 4, to - from - 4); ss >> start; if (!ss || start <= 0) throw pgm_exception("format error (number)"); }
+            repeat.start = (index_t)(start - 1);
+            auto orig_entry = seqs2.find(name);
+            if (orig_entry == seqs2.end()) throw pgm_exception("unknown sequence name: " + name);
+            size_t orig = repeat.start;
+            repeat.len = (index_t)-1;
+            while (std::getline(in, line)) {
+                line = strip_ws(line);
+                if (line.compare(0, 22, "**********************") == 0) break;
+                for (char &c : line) if (c == '-' || c == ' ' || c == '\n' || c == '\t' || c == '\r') c = '_';
+                if (repeat.len != (index_t)-1 && line.size() != repeat.len) throw pgm_exception("repeat unit lengths differ");
+                repeat.len = (index_t)line.size();
+                for (index_t i = 0; i < repeat.len; ++i)
+                    if (line[i] != '_') {
+                        repeat.tr_hom.push_back((int)i);
+                        if (orig >= orig_entry->second.size() || orig_entry->second[orig] != line[i]) throw pgm_exception("character mismatch in repeat of \"" + name + "\"");
+                        ++orig;
+                    }
+            }
+            map[name].push_back(repeat);
+        }
+    }
+    std::cerr << "found " << n_repeats << " repeats in " << n_sequences << " sequences" << std::endl;
+    return map;
+}
+
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
                                                  const PhyTree &tree, const CSProfile *csprofile,
-                                                 const ModelFactory &model_factory) {
+                                                 const ModelFactory &model_factory,
+                                                 const std::map<std::string, std::vector<repeat_t>> *repeats) {
     const auto tl0 = std::chrono::steady_clock::now();
     std::vector<Node> nodes;
     int root = collect(tree, nodes);
@@ -222,6 +293,21 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         }
     }
 
+    if (repeats && !repeats->empty()) {   // tandem-repeat annotation of the leaves (ProgressiveAlignment.cpp:30-38)
+        for (int li : leaves) {
+            Node &nd = nodes[li];
+            auto it2 = repeats->find(nd.tree->getName());
+            if (it2 == repeats->end()) continue;
+            for (const repeat_t &rep : it2->second) {
+                std::vector<int> tr_hom(nd.res.graph.size(), -1);
+                if ((size_t)rep.start + 1 + rep.tr_hom.size() > tr_hom.size()) error("repeat beyond the end of sequence %s", nd.tree->getName().c_str());
+                std::copy(rep.tr_hom.begin(), rep.tr_hom.end(), tr_hom.begin() + rep.start + 1);
+                nd.res.tr_homologies.push_back(tr_hom);
+                nd.res.tr_source.push_back(nd.tree->getName());
+            }
+            nd.res.graph.addRepeats(nd.res.tr_homologies);
+        }
+    }
     if (getenv("PGM_HOST_PROFILE"))
         fprintf(stderr, "leaves: %zu, %.1f ms\n", leaves.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     // ---- internal nodes, one guide-tree level per batch (ProgressiveAlignment.h:413-476) ----
@@ -315,6 +401,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             result.graph = anc.graph;
             extend_alignment(a, result, anc.mapping1, r1.aligned_sequences, L == 1);
             extend_alignment(a, result, anc.mapping2, r2.aligned_sequences, L == 1);
+            if (!r1.tr_homologies.empty() || !r2.tr_homologies.empty()) {   // ProgressiveAlignment.h:455-456, 468
+                extend_tr_homologies(result, anc.mapping1, r1.tr_homologies, r1.tr_source);
+                extend_tr_homologies(result, anc.mapping2, r2.tr_homologies, r2.tr_source);
+            }
             if (!cmdlineopts.profile_file.empty() || cmdlineopts.ancestral_flag) {
                 result.profiles.insert(r1.profiles.begin(), r1.profiles.end());
                 result.profiles.insert(r2.profiles.begin(), r2.profiles.end());
@@ -324,6 +414,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 if (r2.aligned_sequences.size() > 1) ancestral_seq(a, result, create_ancestral_seq_name(r2.aligned_sequences), r2.graph, &anc.mapping2, anc.is_matched, p.model2);
                 ancestral_seq(a, result, create_ancestral_seq_name(result.aligned_sequences), result.graph, nullptr, anc.is_matched, p.model);
             }
+            if (cmdlineopts.repeats_flag) nd.tr_note = "TR indels at " + create_ancestral_seq_name(result.aligned_sequences) + ": " + std::to_string(ar[k].n_tr_indels);   // (:470-473)
+            if (repeats && !repeats->empty()) result.graph.addRepeats(result.tr_homologies);   // (:468; with no annotation at all the merged graph has no repeat edges either way)
             // children are no longer needed (the reference copies them by value and drops them)
             r1 = ProgressiveAlignmentResult();
             r2 = ProgressiveAlignmentResult();
@@ -340,6 +432,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             fprintf(stderr, "    post: plans %.1f ms, node profiles %.1f, edges / graphs / extend %.1f\n", std::chrono::duration<double, std::milli>(tq0 - tp2).count(),
                     std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tp3 - tq1).count());
     }
+    if (cmdlineopts.repeats_flag)   // the reference prints them as its recursion returns: post-order, which is the order of `nodes`
+        for (const Node &nd : nodes) if (!nd.tr_note.empty()) std::cerr << nd.tr_note << std::endl;
     ProgressiveAlignmentResult out = std::move(nodes[root].res);
     if (getenv("PGM_HOST_PROFILE"))
         fprintf(stderr, "[%.1f ms] root result taken\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());

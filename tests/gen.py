@@ -68,3 +68,35 @@ if __name__ == "__main__":
         sys.stdout.write(fasta(gen_codon(n, L, seed)))
     else:
         sys.stdout.write(fasta(gen(n, L, seed)))
+
+
+def gen_repeat_family(n, L, seed, unit_len=7, sub=0.08, indel=0.01, annotate_every=1):
+    """A family (gen) whose members each carry a tandem-repeat region — 2-5 copies of a family-wide unit, with substitutions and
+    deletions inside the copies — and the T-REKS report that annotates those regions (the format `--read_repeats` parses,
+    reference src/RepeatDetectionTReks.cpp:62-151): per sequence a '>' line, a header line 'Length: ... from S to E ...' (S
+    1-based, in the sequence after start stripping) and the aligned units, one per line ('-' = gap), up to a line of asterisks.
+    Returns (sequences, report text)."""
+    rng = random.Random(seed * 7919 + 13)
+    alphabet = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = gen(n, L, seed, sub, indel)
+    unit = [rng.choice(alphabet) for _ in range(unit_len)]
+    out, trd = [], []
+    for i, s in enumerate(seqs):
+        if s[0] == "M":
+            s = "A" + s[1:]   # (a leading M would be stripped before the repeats are mapped: keep the coordinates simple)
+        units = []
+        for _ in range(rng.randint(2, 5)):
+            u = []
+            for ch in unit:
+                r = rng.random()
+                u.append("-" if r < 0.08 else (rng.choice(alphabet) if r < 0.18 else ch))
+            if all(x == "-" for x in u):
+                u[0] = unit[0]
+            units.append("".join(u))
+        pos = rng.randint(5, len(s) - 5)
+        region = "".join(u.replace("-", "") for u in units)
+        out.append(s[:pos] + region + s[pos:])
+        if i % annotate_every == 0:
+            trd.append(">seq%04d\nLength: %d residues - nb: %d  from  %d to %d - Psim:0.80 region Length:%d\n%s\n**********************\n\n"
+                       % (i, unit_len, len(units), pos + 1, pos + len(region), len(region), "\n".join(units)))
+    return out, "".join(trd)

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import gen  # noqa: E402
 
 ONLY = None
-if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral)
+if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral | repeats)
     i = sys.argv.index("--only")
     ONLY = sys.argv[i + 1]
     del sys.argv[i:i + 2]
@@ -96,8 +96,38 @@ def ancestral():
     w("md5.json", json.dumps(md5, indent=1))
 
 
+REPEAT_CASES = [(4, 70, 3, 1), (8, 90, 4, 1), (12, 80, 9, 1), (16, 100, 10, 2), (8, 60, 22, 1), (24, 150, 23, 1)]   # (taxa, length, seed, annotate every k-th sequence)
+
+
+def repeats():
+    """Tandem-repeat edges (Graph::addRepeats, PredIterator's repeat arm, markAlternativePath, n_tr_indels): families whose
+    members carry an annotated repeat region (gen.gen_repeat_family writes the T-REKS report), aligned with
+    `--fasta -R --read_repeats f.trd -t tree` (no Java needed: the report is read, not produced).  Kept: the guide tree, the
+    FASTA, the "TR indels" lines of stderr (per internal node and in total), and for two families the default flow
+    (`--fasta -a --read_repeats`)."""
+    out = []
+    for (n, L, seed, ae) in REPEAT_CASES:
+        seqs, trd = gen.gen_repeat_family(n, L, seed, annotate_every=ae)
+        w("rep.fa.tmp", gen.fasta(seqs))
+        w("rep.trd.tmp", trd)
+        tree = run(["-T", "-i", "0", "rep.fa.tmp"])
+        w("rep.tree.tmp", tree)
+        r = subprocess.run([BIN, "--fasta", "-R", "--read_repeats", "rep.trd.tmp", "-t", "rep.tree.tmp", "rep.fa.tmp"], check=True, capture_output=True, text=True)
+        plain = run(["--fasta", "-t", "rep.tree.tmp", "rep.fa.tmp"])
+        rec = dict(n=n, L=L, seed=seed, annotate_every=ae, tree=tree, out=r.stdout, tr_lines=[ln for ln in r.stderr.splitlines() if "TR indels" in ln],
+                   changes_alignment=(r.stdout != plain))
+        if n <= 8:
+            rec["out_default_flow"] = run(["--fasta", "-a", "--read_repeats", "rep.trd.tmp", "rep.fa.tmp"])
+        out.append(rec)
+    for f in ("rep.fa.tmp", "rep.trd.tmp", "rep.tree.tmp"):
+        os.remove(f)
+    w("repeats.json", json.dumps(out, indent=0))
+
+
 def main():
     os.chdir(HERE)
+    if ONLY == "repeats":
+        return repeats()
     if ONLY == "ancestral":
         return ancestral()
     if ONLY == "nw_trees":
@@ -203,6 +233,7 @@ def main():
     w("md5.json", json.dumps(md5, indent=1))
     full_size()
     ancestral()
+    repeats()
     for f in ("c3.fa.tmp", "pair.fa.tmp", "pair.tree.tmp"):
         os.remove(f)
     print("golden fixtures regenerated in", HERE)

@@ -176,3 +176,22 @@ def test_codon_nw_distance_pairs(oracle_build, tmp_path):
     for seed, p in nw.items():
         (tmp_path / "p.fa").write_text(p["fasta"])
         assert run_oracle(oracle_build, ["--codon", "-a", "-m", "-T", "-i", "0", str(tmp_path / "p.fa")]) == p["ml"], seed
+
+
+def test_tandem_repeat_families(oracle_build, tmp_path):
+    """The repeat-edge branch of the hot function (PredIterator's repeat arm, Graph.h:232-238; markAlternativePath,
+    GraphAlign.h:165-198; n_tr_indels) pinned against the reference binary: `--fasta -R --read_repeats` on families with
+    annotated tandem repeats — FASTA and the "TR indels" lines per internal node identical; two families also through the
+    default flow (guide-tree re-estimation in between)."""
+    cases = json.load(open(os.path.join(GOLD, "repeats.json")))
+    assert sum(c["changes_alignment"] for c in cases) >= 3 and any("1" in ln.split(": ")[-1] for c in cases for ln in c["tr_lines"][:-1])
+    exe = os.path.join(oracle_build, "pgmsa_oracle")
+    for c in cases:
+        seqs, trd = gen.gen_repeat_family(c["n"], c["L"], c["seed"], annotate_every=c["annotate_every"])
+        (tmp_path / "r.fa").write_text(gen.fasta(seqs)); (tmp_path / "r.trd").write_text(trd); (tmp_path / "r.tree").write_text(c["tree"])
+        r = subprocess.run([exe, "--fasta", "-R", "--read_repeats", str(tmp_path / "r.trd"), "-t", str(tmp_path / "r.tree"), str(tmp_path / "r.fa")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == c["out"], c["seed"]
+        assert [ln for ln in r.stderr.splitlines() if "TR indels" in ln] == c["tr_lines"], c["seed"]
+        if "out_default_flow" in c:
+            assert run_oracle(oracle_build, ["--fasta", "-a", "--read_repeats", str(tmp_path / "r.trd"), str(tmp_path / "r.fa")]) == c["out_default_flow"], c["seed"]
