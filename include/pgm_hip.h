@@ -193,7 +193,12 @@ int pgm_mldist_batch(pgm_ctx *ctx, const pgm_mldist_model *model, uint32_t npair
 int pgm_prealigned_counts_batch(pgm_ctx *ctx, uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows,
                                 uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
                                 uint32_t *gaps);
-/* Device time of the kernel of the last pgm_mldist_batch / pgm_prealigned_counts_batch call on this context (ms). */
+/* ---- (f4) DistanceFactoryAngle's cosine matrix — replaces the dense product of reference src/DistanceFactoryAngle.h:100
+ * (`norms^-1 * counts2^T * counts2 * norms^-1`, the default initial distances without -a).  counts: nseq x ncols int32,
+ * row-major (row i = the K-mer counts of sequence i; ncols = DIM^K).  cosine: nseq x nseq doubles, column-major,
+ * cosine(i, j) = (sum_k (c_ik / |c_i|) c_jk) / |c_j| with k ascending (fp64, one multiply and one add per term). */
+int pgm_kmer_cosine(pgm_ctx *ctx, uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine);
+/* Device time of the kernel of the last pgm_mldist_batch / pgm_prealigned_counts_batch / pgm_kmer_cosine call on this context (ms). */
 float pgm_dist_last_kernel_ms(pgm_ctx *ctx);
 
 /* ---- (f1, numeric part) mergeGraphs' node profiles — replaces the P*g products and the L2 normalisation of reference

@@ -15,6 +15,7 @@ int pgmo_nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t gap_open, in
 int pgmo_csprofile_create(uint32_t K, uint32_t ncols, const double *lprofiles, const double *centre,
                           const double *priors, const int8_t *seq, uint32_t L, double tau, const double *pi,
                           const double *p_uniform, double *out);
+int pgmo_kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *out);
 int pgmo_merge_profiles(const pgm_merge_job *job);
 int pgmo_prealigned_counts(uint32_t dim, uint32_t nrows, uint32_t ncols, const int8_t *rows, uint32_t npairs, const uint32_t *pi,
                            const uint32_t *pj, int32_t *counts, uint32_t *gaps);
@@ -40,6 +41,9 @@ struct OracleBackend : Backend {
             error("error while backtracking");
     }
     // f1 / f3 through the oracle's own restatements, so that the golden fixtures (FASTA, --profile_out, newick) pin them too
+    void kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine, int) override {
+        if (pgmo_kmer_cosine(nseq, ncols, counts, cosine) != PGM_OK) error("pgmo_kmer_cosine failed");
+    }
     bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs, int) override {
         for (uint32_t i = 0; i < njobs; ++i)
             if (pgmo_merge_profiles(&jobs[i]) != PGM_OK) error("pgmo_merge_profiles failed");

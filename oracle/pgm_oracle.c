@@ -20,6 +20,7 @@
  *   pgmo_csprofile_create  src/CSProfile.cpp:175-225 (createProfile)
  *   pgmo_merge_profiles    src/GraphAlign.h:569-620 (mergeGraphs: node profiles of the merged graph)
  *   pgmo_prealigned_counts src/DistanceFactoryPrealigned.h:34-90 (pair counts of an alignment)
+ *   pgmo_kmer_cosine       src/DistanceFactoryAngle.h:100 (the cosine matrix of the k-mer count vectors)
  *   pgmo_mldist            src/DistanceFactoryML.h:66-190 (computeDistance / computeMLDist), src/ModelFactory.h:48-67, 104-127
  */
 #include "../include/pgm_hip.h"
@@ -803,5 +804,30 @@ int pgmo_mldist(const pgm_mldist_model *m, uint32_t npairs, const int32_t *count
         var_out[pr] = var;
     }
     free(P);
+    return PGM_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* DistanceFactoryAngle, the dense product (DistanceFactoryAngle.h:100): norms^-1 * counts2^T * counts2 * norms^-1, evaluated
+ * left to right.  counts: nseq x ncols, row-major.  out(i, j), column-major = (sum_k (c_ik * inv_i) * c_jk) * inv_j with k
+ * ascending.  PARITY NOTE: the reference's sum runs in the order of Eigen's GEMM micro-kernel, which the sources do not
+ * show; with this order the BioNJ tree of the binary is reproduced for about two families in three (every BioNJ run ends in an
+ * exact tie that the last bits of the distances decide) — tests pin the fixtures where it is, DESIGN.md states the rate. */
+int pgmo_kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *out) {
+    if (!counts || !out || ncols == 0) return PGM_ERR_INVALID;
+    double *inv = (double *)malloc(sizeof(double) * (nseq ? nseq : 1));
+    if (!inv) return PGM_ERR_NOMEM;
+    for (uint32_t i = 0; i < nseq; ++i) {
+        unsigned long long ss = 0;
+        for (uint32_t k = 0; k < ncols; ++k) { const long long c = counts[(size_t)i * ncols + k]; ss += (unsigned long long)(c * c); }
+        inv[i] = 1.0 / sqrt((double)ss);
+    }
+    for (uint32_t j = 0; j < nseq; ++j)
+        for (uint32_t i = 0; i < nseq; ++i) {
+            double acc = 0.0;
+            for (uint32_t k = 0; k < ncols; ++k) acc += ((double)counts[(size_t)i * ncols + k] * inv[i]) * (double)counts[(size_t)j * ncols + k];
+            out[(size_t)i + (size_t)nseq * j] = acc * inv[j];
+        }
+    free(inv);
     return PGM_OK;
 }

@@ -58,7 +58,7 @@ EXPORTS = [
     "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_align_batch_stage_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_last_kernel_ms", "pgm_csprofile_load", "pgm_csprofile_create_batch",
-    "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_dist_last_kernel_ms",
+    "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
     "pgm_merge_profiles_batch", "pgm_merge_last_kernel_ms",
 ]
 
@@ -96,6 +96,7 @@ def _load():
         "pgm_csprofile_last_kernel_ms": (C.c_float, [vp]),
         "pgm_mldist_batch": (C.c_int, [vp, C.POINTER(pgm_mldist_model), u32, C.POINTER(i32), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 3),
         "pgm_prealigned_counts_batch": (C.c_int, [vp, u32, u32, u32, C.POINTER(C.c_int8), u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),
+        "pgm_kmer_cosine": (C.c_int, [vp, u32, u32, C.POINTER(i32), C.POINTER(C.c_double)]),
         "pgm_dist_last_kernel_ms": (C.c_float, [vp]),
         "pgm_merge_profiles_batch": (C.c_int, [vp, u32, C.POINTER(pgm_merge_job)]),
         "pgm_merge_last_kernel_ms": (C.c_float, [vp]),

@@ -61,6 +61,10 @@ struct HipBackend : Backend {
         if (rc != PGM_OK) error("pgm_prealigned_counts_batch failed (%d): %s", rc, pgm_last_error());
         return true;
     }
+    void kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine, int worker) override {
+        int rc = pgm_kmer_cosine(ctx_of(worker), nseq, ncols, counts, cosine);
+        if (rc != PGM_OK) error("pgm_kmer_cosine failed (%d): %s", rc, pgm_last_error());
+    }
     bool merge_profiles_batch(uint32_t njobs, const pgm_merge_job *jobs, int worker) override {
         int rc = pgm_merge_profiles_batch(ctx_of(worker), njobs, jobs);
         if (rc != PGM_OK) error("pgm_merge_profiles_batch failed (%d): %s", rc, pgm_last_error());

@@ -447,6 +447,44 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     return distances;
 }
 
+DistanceMatrix angleDistances(const Alphabet &a, const std::map<std::string, sequence_t> &sequences, const std::vector<std::string> &order) {
+    const uint32_t n = (uint32_t)order.size(), D = (uint32_t)a.DIM, ncols = D * D;   // K = 2 for both alphabets
+    DistanceMatrix distances((int)n);
+    std::vector<int32_t> counts((size_t)n * ncols, 0);
+    std::vector<double> seq_len(n);
+    for (uint32_t i = 0; i < n; ++i) {   // DistanceFactoryAngle.h:63-94
+        const sequence_t &seq = sequences.at(order[i]);
+        seq_len[i] = (double)seq.size();
+        int prev = -1;
+        for (size_t j = 0; j < seq.size(); ++j) {
+            int v = a.value(seq[j]);
+            if (v < 0 || v >= (int)D) v = -1;
+            if (prev != -1 && v != -1) counts[(size_t)i * ncols + (size_t)prev * D + (size_t)v] += 1;
+            prev = v;
+        }
+    }
+    Backend &be = default_backend();
+    const auto t0 = std::chrono::steady_clock::now();
+    be.kmer_cosine(n, ncols, counts.data(), distances.distances.data());   // :100
+    be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const bool ml = cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag;
+    for (double &d : distances.distances) {   // :101-105
+        d = -1.0 * std::log((d * d + 0.4) / 1.4);
+        if (!ml) {
+            const double e = std::exp(d);
+            d = -0.5 * (5.0 * e - std::sqrt(45.0 * (e * e) - 20.0 * e)) * (1.0 / e);
+        }
+    }
+    for (uint32_t j = 0; j < n; ++j)   // :107-113: variances = distances / ((len_i + len_j) / 2), at least 1e-5
+        for (uint32_t i = 0; i < n; ++i) {
+            double v = 1.0 / ((seq_len[j] + seq_len[i]) / 2);
+            v *= distances.D((int)i, (int)j);
+            distances.V((int)i, (int)j) = std::max(v, 1e-5);
+        }
+    dump_distances(distances);
+    return distances;
+}
+
 PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs, const ModelFactory *mf, bool prealigned) {
     if (seqs.size() < 2) error("cannot construct tree from < 2 sequences");
     if (prealigned) {
@@ -463,10 +501,13 @@ PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
         return t;
     }
-    if (!cmdlineopts.nwdist_flag)
-        error("initial guide tree: only -a/--nwdist (DistanceFactoryAlign) is built here; pass --tree or -a");
     std::vector<std::string> order;
     for (const auto &kv : seqs) order.push_back(kv.first);  // std::map key order (TreeNJ.h:34-39)
+    if (!cmdlineopts.nwdist_flag) {   // DistanceFactory::getDefault (DistanceFactory.cpp:9-20): the k-mer angle distances
+        DistanceMatrix dist = angleDistances(a, seqs, order);
+        for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
+        return midpointRoot(buildNJTree(order, dist));
+    }
     DistanceFactoryAlign df(a, mf);
     DistanceMatrix dist = df.computePwDistances(seqs, order);
     for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }

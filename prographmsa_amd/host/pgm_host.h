@@ -237,6 +237,8 @@ struct Backend {
     // false = this backend has no such kernel (the host estimator is used)
     virtual bool mldist_batch(const pgm_mldist_model &, uint32_t, const int32_t *, const uint32_t *, const double *, double *, double *, int = 0) { return false; }
     virtual bool prealigned_counts_batch(uint32_t, uint32_t, uint32_t, const int8_t *, uint32_t, const uint32_t *, const uint32_t *, int32_t *, uint32_t *, int = 0) { return false; }
+    // cosine matrix of the k-mer count vectors (DistanceFactoryAngle.h:100): counts nseq x ncols row-major -> nseq x nseq column-major
+    virtual void kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine, int worker = 0) = 0;
     // node profiles of a batch of merged graphs on the device (numeric part); false = host arithmetic
     virtual bool merge_profiles_batch(uint32_t, const pgm_merge_job *, int = 0) { return false; }
     double seconds_merge_profiles = 0;
@@ -394,6 +396,9 @@ public:
 private:
     std::vector<int32_t> scoring_matrix_;   // (DIM+1)^2 column-major
 };
+// DistanceFactoryAngle<ALPHABET, 2> (DistanceFactoryAngle.h:55-131): the default initial distances (no -a): cosine of the 2-mer
+// count vectors, turned into a distance
+DistanceMatrix angleDistances(const Alphabet &a, const std::map<std::string, sequence_t> &sequences, const std::vector<std::string> &order);
 class DistanceFactoryPrealigned : public DistanceFactoryML {   // DistanceFactoryPrealigned.h:34-90
 public:
     DistanceFactoryPrealigned(const Alphabet &a, const ModelFactory *mf) : DistanceFactoryML(a, mf) {}

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import gen  # noqa: E402
 
 ONLY = None
-if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral | repeats)
+if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral | repeats | angle)
     i = sys.argv.index("--only")
     ONLY = sys.argv[i + 1]
     del sys.argv[i:i + 2]
@@ -124,8 +124,33 @@ def repeats():
     w("repeats.json", json.dumps(out, indent=0))
 
 
+def angle():
+    """The reference's flow WITHOUT -a: initial guide tree from the k-mer angle distances (DistanceFactoryAngle.h:55-131), then the
+    usual two rounds of alignment + tree re-estimation and the final alignment.  BASELINE config 2 as worded (`--fasta c2.fa`),
+    config 3's progressive part (`--fasta --mldist c3.fa`, ~30 s), the small families in text; and the initial trees alone
+    (-T -i 0) of the twelve NW_TREE_CASES families: every BioNJ run ends in an exact tie that the last bits of the distances
+    decide, and the cosine matrix comes out of Eigen's GEMM, whose summation order the sources do not show — the restatement
+    reproduces about two trees in three (tests/test_oracle_golden.py lists which), the FASTA of the full flow every time."""
+    md5 = json.load(open("md5.json"))
+    w("c1.default.out.fa", run(["--fasta", "c1.fa"]))
+    w("cd1.default.out.fa", run(["--codon", "--fasta", "cd1.fa"]))
+    md5["c2.default.out.fa"] = hashlib.md5(run(["--fasta", "c2.fa"]).encode()).hexdigest()
+    w("c3.fa.tmp", gen.fasta(gen.gen(256, 1000, 3)))
+    md5["c3.default_m.out.fa"] = hashlib.md5(run(["--fasta", "--mldist", "c3.fa.tmp"]).encode()).hexdigest()
+    os.remove("c3.fa.tmp")
+    out = []
+    for (n, L, seed, sub, indel) in NW_TREE_CASES:
+        w("ang.fa.tmp", gen.fasta(gen.gen(n, L, seed, sub=sub, indel=indel)))
+        out.append(dict(n=n, L=L, seed=seed, sub=sub, indel=indel, tree=run(["-T", "-i", "0", "ang.fa.tmp"]), fasta=run(["--fasta", "ang.fa.tmp"])))
+    os.remove("ang.fa.tmp")
+    w("angle_trees.json", json.dumps(out, indent=0))
+    w("md5.json", json.dumps(md5, indent=1))
+
+
 def main():
     os.chdir(HERE)
+    if ONLY == "angle":
+        return angle()
     if ONLY == "repeats":
         return repeats()
     if ONLY == "ancestral":
@@ -234,7 +259,8 @@ def main():
     full_size()
     ancestral()
     repeats()
-    for f in ("c3.fa.tmp", "pair.fa.tmp", "pair.tree.tmp"):
+    angle()
+    for f in ("pair.fa.tmp", "pair.tree.tmp"):
         os.remove(f)
     print("golden fixtures regenerated in", HERE)
 

@@ -124,3 +124,16 @@ def mldist(model, counts, gaps, seqlen):
     rc = _l.pgmo_mldist(C.byref(model), n, P(counts, C.c_int32), P(gaps, C.c_uint32), P(seqlen, C.c_double), P(dist, C.c_double), P(var, C.c_double))
     assert rc == 0
     return dist, var
+
+
+_l.pgmo_kmer_cosine.restype = C.c_int
+_l.pgmo_kmer_cosine.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+
+
+def kmer_cosine(counts):
+    """counts: (nseq, ncols) int32 -> flat nseq * nseq float64 (column-major)."""
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(counts.shape[0] * counts.shape[0])
+    rc = _l.pgmo_kmer_cosine(counts.shape[0], counts.shape[1], counts.ctypes.data_as(C.POINTER(C.c_int32)), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out

@@ -169,3 +169,18 @@ def test_mldist_kernel_against_the_oracle(ctx, flags):
     else:
         assert np.max(np.abs(dist - rd) / np.maximum(np.abs(rd), 1e-300)) <= 1e-12
         assert np.max(np.abs(var - rv) / np.maximum(np.abs(rv), 1e-300)) <= 1e-9   # (the variance is -1 / f'' of the last Newton step: a difference of two large sums)
+
+
+@pytest.mark.parametrize("nseq,ncols", [(1, 400), (7, 400), (64, 400), (257, 400), (33, 3721)])
+def test_kmer_cosine_bit_exact(ctx, nseq, ncols):
+    """pgm_kmer_cosine_kernel vs the oracle's pgmo_kmer_cosine (DistanceFactoryAngle.h:100): same order of the fp64 operations, bit for bit."""
+    import oracle_lib
+    import prographmsa_amd as pg
+    rng = np.random.default_rng(nseq * 1000 + ncols)
+    counts = rng.poisson(0.6, (nseq, ncols)).astype(np.int32)
+    counts[:, 0] += 1                                   # no all-zero row (a sequence shorter than K would have one: 1/0 on both sides)
+    out = np.zeros(nseq * nseq)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    pg.check(pg.lib.pgm_kmer_cosine(ctx.handle, nseq, ncols, P(counts, C.c_int32), P(out, C.c_double)))
+    ref = oracle_lib.kmer_cosine(counts)
+    assert np.array_equal(out.view(np.uint64), ref.view(np.uint64))

@@ -195,3 +195,34 @@ def test_tandem_repeat_families(oracle_build, tmp_path):
         assert [ln for ln in r.stderr.splitlines() if "TR indels" in ln] == c["tr_lines"], c["seed"]
         if "out_default_flow" in c:
             assert run_oracle(oracle_build, ["--fasta", "-a", "--read_repeats", str(tmp_path / "r.trd"), str(tmp_path / "r.fa")]) == c["out_default_flow"], c["seed"]
+
+
+# Families of tests/golden/angle_trees.json for which the restatement of the k-mer angle distances (oracle: pgmo_kmer_cosine,
+# sequential k) does not give the reference binary's output: the final BioNJ join is an exact tie that the last bits of the
+# distances decide, and those come out of Eigen's GEMM, whose summation order the sources do not show.
+ANGLE_TREE_FLIPS = {133400, 545337, 295589}     # initial tree (-T -i 0) rooted on the other side of the tie
+ANGLE_FASTA_DIFFERS = {545337}                  # ... and the difference survives the two re-estimation rounds of the default flow
+
+
+def test_default_flow_without_nwdist(oracle_build, tmp_path):
+    """The reference's default flow from sequences alone, WITHOUT -a (initial distances: DistanceFactoryAngle): BASELINE config 1 /
+    config 2 inputs as worded (`--fasta c2.fa`), a codon family; the 256 x 1000 family with --mldist behind PGM_SLOW_TESTS."""
+    md5 = json.load(open(os.path.join(GOLD, "md5.json")))
+    assert run_oracle(oracle_build, ["--fasta", os.path.join(GOLD, "c1.fa")]) == gold("c1.default.out.fa")
+    assert run_oracle(oracle_build, ["--codon", "--fasta", os.path.join(GOLD, "cd1.fa")]) == gold("cd1.default.out.fa")
+    assert hashlib.md5(run_oracle(oracle_build, ["--fasta", os.path.join(GOLD, "c2.fa")]).encode()).hexdigest() == md5["c2.default.out.fa"]
+    if os.environ.get("PGM_SLOW_TESTS"):
+        (tmp_path / "c3.fa").write_text(gen.fasta(gen.gen(256, 1000, 3)))
+        assert hashlib.md5(run_oracle(oracle_build, ["--fasta", "--mldist", str(tmp_path / "c3.fa")]).encode()).hexdigest() == md5["c3.default_m.out.fa"]
+
+
+def test_angle_guide_trees_and_the_exact_tie(oracle_build, tmp_path):
+    cases = json.load(open(os.path.join(GOLD, "angle_trees.json")))
+    flips, differs = set(), set()
+    for c in cases:
+        (tmp_path / "k.fa").write_text(gen.fasta(gen.gen(c["n"], c["L"], c["seed"], sub=c["sub"], indel=c["indel"])))
+        if run_oracle(oracle_build, ["-T", "-i", "0", str(tmp_path / "k.fa")]) != c["tree"]:
+            flips.add(c["seed"])
+        if run_oracle(oracle_build, ["--fasta", str(tmp_path / "k.fa")]) != c["fasta"]:
+            differs.add(c["seed"])
+    assert flips == ANGLE_TREE_FLIPS and differs == ANGLE_FASTA_DIFFERS   # 9 of 12 trees, 11 of 12 alignments identical
