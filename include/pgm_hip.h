@@ -152,8 +152,27 @@ int pgm_nw_pairs_batch(pgm_ctx *ctx, uint32_t dim, const int32_t *score, int32_t
                        int32_t gap_extend, uint32_t nseq, const int8_t *syms,
                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
                        const uint32_t *pj, int32_t *counts, uint32_t *gaps);
-/* Device-time of the NW kernels of the last pgm_nw_pairs_batch call on this context (ms). */
+/* The same in two halves, so that a caller keeps TWO tiles of pairs in flight on one context: submit returns once the tile's
+ * inputs are staged and its kernel and copies are enqueued (ticket 0 or 1); wait blocks until that tile's results are in
+ * `counts` / `gaps` (the pointers given to submit, which must stay valid until then).  While the host waits for tile k and
+ * copies its count matrices out, the kernel of tile k+1 runs.  A third submit without a wait is refused (PGM_ERR_INVALID).
+ * flags: PGM_NW_REDUCED — `counts` receives two int32 per pair, (Σ_s counts(s,s), Σ counts), instead of the dim x dim matrix:
+ * all the p-distance of DistanceFactoryML.h:143-146 reads (the default flow without --mldist).
+ * Result buffers from pgm_host_alloc (pinned) are written by the D2H copy directly; any other memory goes through the
+ * library's pinned staging block and one host copy.  One host thread per context. */
+#define PGM_NW_REDUCED 1u
+int pgm_nw_pairs_submit(pgm_ctx *ctx, uint32_t dim, const int32_t *score, int32_t gap_open,
+                        int32_t gap_extend, uint32_t nseq, const int8_t *syms,
+                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
+                        const uint32_t *pj, uint32_t flags, int32_t *counts, uint32_t *gaps, int *ticket);
+int pgm_nw_pairs_wait(pgm_ctx *ctx, int ticket);
+/* Device-time of the NW kernel of the tile the last pgm_nw_pairs_wait / pgm_nw_pairs_batch on this context completed (ms;
+ * with two tiles in flight the second kernel's blocks wait for the first's to leave, so the times of overlapping tiles
+ * overlap too). */
 float pgm_nw_last_kernel_ms(pgm_ctx *ctx);
+/* Pinned host memory for result buffers (NULL on failure). */
+void *pgm_host_alloc(size_t bytes);
+void pgm_host_free(void *p);
 
 /* ---- (B3) CSProfile::createProfile — replaces reference src/CSProfile.cpp:175-225 ------
  * load: K context profiles with `ncols` window columns.  lprofiles: K x ncols x 21 doubles

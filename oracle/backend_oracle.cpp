@@ -34,12 +34,23 @@ struct OracleBackend : Backend {
     // PGM_FARM_WORKERS=k: the farms of the host scaffolding (all-pairs tiles, jobs of a guide-tree level, leaves) run with k
     // host threads over this (stateless, re-entrant) CPU oracle: the 1-vs-k-workers identity tests of tests/test_cpu_host.py
     int workers() const override { const char *e = getenv("PGM_FARM_WORKERS"); return e ? std::max(1, atoi(e)) : 1; }
-    void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
-                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
+    int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
+                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, uint32_t flags, int32_t *counts,
                         uint32_t *gaps, int) override {
-        if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps) != PGM_OK)
+        if (flags & 1u) {   // PGM_NW_REDUCED: (ident, total) of the count matrix
+            std::vector<int32_t> full((size_t)npairs * dim * dim);
+            if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, full.data(), gaps) != PGM_OK) error("error while backtracking");
+            for (uint32_t p = 0; p < npairs; ++p) {
+                int32_t ident = 0, total = 0;
+                for (uint32_t a = 0; a < dim; ++a)
+                    for (uint32_t c = 0; c < dim; ++c) { total += full[((size_t)p * dim + c) * dim + a]; if (a == c) ident += full[((size_t)p * dim + c) * dim + a]; }
+                counts[2 * (size_t)p] = ident; counts[2 * (size_t)p + 1] = total;
+            }
+        } else if (pgmo_nw_pairs_batch(dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps) != PGM_OK)
             error("error while backtracking");
+        return 0;
     }
+    void nw_pairs_wait(int, int) override {}
     // f1 / f3 through the oracle's own restatements, so that the golden fixtures (FASTA, --profile_out, newick) pin them too
     void kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine, int) override {
         if (pgmo_kmer_cosine(nseq, ncols, counts, cosine) != PGM_OK) error("pgmo_kmer_cosine failed");

@@ -18,6 +18,7 @@ PGMSA_PATH = os.path.join(_HERE, "bin", "pgmsa")
 PGM_OK, PGM_ERR_INVALID, PGM_ERR_DEVICE, PGM_ERR_BACKTRACK, PGM_ERR_NOMEM = 0, 1, 2, 3, 4
 PGM_GAP = 0xFFFFFFFF
 PGM_BATCH_KEEP_MATRICES = 1
+PGM_NW_REDUCED = 1
 
 
 class pgm_graph(C.Structure):
@@ -57,7 +58,7 @@ EXPORTS = [
     "pgm_device_count", "pgm_ctx_create", "pgm_ctx_destroy", "pgm_last_error", "pgm_ctx_device_info",
     "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_align_batch_stage_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
-    "pgm_nw_pairs_batch", "pgm_nw_last_kernel_ms", "pgm_csprofile_load", "pgm_csprofile_create_batch",
+    "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
     "pgm_merge_profiles_batch", "pgm_merge_last_kernel_ms",
 ]
@@ -89,6 +90,11 @@ def _load():
         "pgm_align_batch_read_matrices": (C.c_int, [vp, vp, u32] + [C.POINTER(C.c_float)] * 5),
         "pgm_nw_pairs_batch": (C.c_int, [vp, u32, C.POINTER(i32), i32, i32, u32, C.POINTER(C.c_int8), C.POINTER(u32), u32,
                                          C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),
+        "pgm_nw_pairs_submit": (C.c_int, [vp, u32, C.POINTER(i32), i32, i32, u32, C.POINTER(C.c_int8), C.POINTER(u32), u32,
+                                          C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(i32), C.POINTER(u32), C.POINTER(C.c_int)]),
+        "pgm_nw_pairs_wait": (C.c_int, [vp, C.c_int]),
+        "pgm_host_alloc": (vp, [C.c_size_t]),
+        "pgm_host_free": (None, [vp]),
         "pgm_nw_last_kernel_ms": (C.c_float, [vp]),
         "pgm_csprofile_load": (C.c_int, [vp, u32, u32] + [C.POINTER(C.c_double)] * 3),
         "pgm_csprofile_create_batch": (C.c_int, [vp, u32, C.POINTER(C.c_int8), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 4

@@ -43,8 +43,11 @@ static const char *tools_env(const char *) { return nullptr; }
             return fail(PGM_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
+struct PgmNwState;
 struct pgm_ctx {
     int device = 0;
+    PgmNwState *nw = nullptr;        // the all-pairs stage's two tiles in flight (pgm_nw_capi.inc)
+    int nw_per_cu = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
@@ -213,9 +216,11 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     return PGM_OK;
 }
 
+static void nw_state_free(PgmNwState *st);
 void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    nw_state_free(ctx->nw);
     if (ctx->cs_lprofiles) (void)hipFree(ctx->cs_lprofiles);
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);

@@ -22,12 +22,14 @@ struct PgmNwArgs {
     uint32_t dim;            // alphabet size D; scoring matrix is (D+1)^2 column-major
     int32_t gap_open, gap_extend;
     uint32_t npairs;
+    uint32_t reduced;        // 1: counts holds (ident, total) per pair — Σ diagonal and Σ all entries of the count matrix, what the
+                             // p-distance needs (DistanceFactoryML.h:143-146) — instead of the matrix itself
     const int32_t *score;
     const int8_t *syms;
     const uint32_t *offs;
     const uint32_t *pi, *pj;
     const uint32_t *order;   // pair processing order (longest first)
-    int32_t *counts;         // npairs x D x D, zero-initialised
+    int32_t *counts;         // npairs x D x D, zero-initialised (reduced: npairs x 2, written)
     uint32_t *gaps;          // npairs
     uint32_t *queue;         // work counter, zero-initialised
     uint32_t *dirs;          // per wave slot: dir_words_per_slot uint32
@@ -163,6 +165,7 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
             uint32_t gaps = 0;
             bool open1 = false, open2 = false;
             int32_t *cnt = A.counts + (size_t)p * A.dim * A.dim;
+            int ident = 0, total = 0;
             int y = L2, x = L1;
             while (y != 0 && x != 0) {
                 const int bb = (y - 1) / BR, rr = (y - 1) % BR, l = rr / R;
@@ -172,7 +175,10 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                 if (dir == 0) {
                     const int a = __builtin_amdgcn_readfirstlane((int)s1[x - 1]);
                     const int c = __builtin_amdgcn_readfirstlane((int)s2[y - 1]);
-                    if (lane == 0 && a < (int)A.dim && c < (int)A.dim) atomicAdd(&cnt[a + (int)A.dim * c], 1);
+                    if (a < (int)A.dim && c < (int)A.dim) {
+                        if (A.reduced) { ++total; ident += (a == c) ? 1 : 0; }
+                        else if (lane == 0) atomicAdd(&cnt[a + (int)A.dim * c], 1);
+                    }
                     open1 = false; open2 = false;
                     --x; --y;
                 } else if (dir == 1) {
@@ -186,6 +192,7 @@ __global__ void __launch_bounds__(WAVES * 64) pgm_nw_kernel(PgmNwArgs A) {
                 }
             }
             if (lane == 0) A.gaps[p] = gaps;
+            if (lane == 0 && A.reduced) { A.counts[2 * (size_t)p] = ident; A.counts[2 * (size_t)p + 1] = total; }
         }
     }
 }

@@ -24,10 +24,10 @@ def sorted_pairs(lengths):
 
 
 def tile_size(npairs, workers, override=None):
-    """Pairs per tile: four tiles per worker, at least 256 pairs (host/distance.cpp uses the same rule)."""
+    """Pairs per tile: three tiles per worker, at least 256 pairs (host/distance.cpp uses the same rule, and says why)."""
     if override:
         return max(1, int(override))
-    return max(256, (npairs + 4 * workers - 1) // (4 * workers))
+    return max(256, (npairs + 3 * workers - 1) // (3 * workers))
 
 
 class TicketQueue:

@@ -43,12 +43,24 @@ struct HipBackend : Backend {
         int rc = pgm_align_graphs_batch(ctx_of(worker), njobs, g1, g2, model, scores, out);
         if (rc != PGM_OK && rc != PGM_ERR_BACKTRACK) error("pgm_align_graphs_batch failed (%d): %s", rc, pgm_last_error());
     }
-    void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
-                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, int32_t *counts,
+    int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
+                        const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, uint32_t flags, int32_t *counts,
                         uint32_t *gaps, int worker) override {
-        int rc = pgm_nw_pairs_batch(ctxs[(size_t)worker % ctxs.size()], dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, counts, gaps);
-        if (rc != PGM_OK) error("pgm_nw_pairs_batch failed (%d): %s", rc, pgm_last_error());
+        int ticket = -1;
+        int rc = pgm_nw_pairs_submit(ctxs[(size_t)worker % ctxs.size()], dim, score, go, ge, nseq, syms, offs, npairs, pi, pj, flags, counts, gaps, &ticket);
+        if (rc != PGM_OK) error("pgm_nw_pairs_submit failed (%d): %s", rc, pgm_last_error());
+        return ticket;
     }
+    void nw_pairs_wait(int ticket, int worker) override {
+        int rc = pgm_nw_pairs_wait(ctxs[(size_t)worker % ctxs.size()], ticket);
+        if (rc != PGM_OK) error("pgm_nw_pairs_wait failed (%d): %s", rc, pgm_last_error());
+    }
+    void *host_alloc(size_t bytes) override {
+        void *p = pgm_host_alloc(bytes);
+        if (!p) error("pgm_host_alloc(%zu) failed", bytes);
+        return p;
+    }
+    void host_free(void *p) override { pgm_host_free(p); }
     bool mldist_batch(const pgm_mldist_model &m, uint32_t npairs, const int32_t *counts, const uint32_t *gaps, const double *seqlen,
                       double *dist, double *var, int worker) override {
         int rc = pgm_mldist_batch(ctxs[(size_t)worker % ctxs.size()], &m, npairs, counts, gaps, seqlen, dist, var);

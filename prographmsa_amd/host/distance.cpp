@@ -83,13 +83,22 @@ distvar_t DistanceFactoryML::computeDistance(const std::vector<int32_t> &counts,
     double ident = 0, total = 0;
     for (int i = 0; i < n; ++i) ident += counts[i + n * i];
     for (int32_t c : counts) total += c;
+    return computeDistance(ident, total, &counts, gaps, seqlen);
+}
+
+// (ident, total) are sums of integers, exact in any order: the all-pairs stage reduces them on the device when nothing else of the
+// count matrix is read (no --mldist: counts == nullptr)
+distvar_t DistanceFactoryML::computeDistance(double ident, double total, const std::vector<int32_t> *counts, index_t gaps, double seqlen) const {
+    double DIST_MAX, VAR_MAX, VAR_MIN;
+    consts(alphabet, DIST_MAX, VAR_MAX, VAR_MIN);
     double dist0 = 1.0 - ident / total;
     double dist, var;
     if (cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag) {
         if (total == 0 || dist0 > 0.85) { dist = dist0 = DIST_MAX; var = VAR_MAX; }
         else { dist = dist0 = -std::log(1.0 - dist0 - 0.2 * dist0 * dist0); var = dist / total; }
         if (total > 0 && ident != total) {
-            distvar_t dv = computeMLDist(counts, gaps, seqlen, dist, var);
+            if (!counts) error("computeDistance: the ML estimate needs the count matrix");
+            distvar_t dv = computeMLDist(*counts, gaps, seqlen, dist, var);
             dist = dv.dist;
             var = dv.var;
         }
@@ -115,7 +124,7 @@ static void dump_distances(const DistanceMatrix &d) {
     f.write((const char *)d.variances.data(), 8 * d.variances.size());
 }
 
-void DistanceFactoryML::computeDistances(const std::vector<int32_t> &counts, const std::vector<uint32_t> &gaps, const std::vector<double> &seqlen,
+void DistanceFactoryML::computeDistances(const int32_t *counts, const uint32_t *gaps, const std::vector<double> &seqlen,
                                          const std::vector<uint32_t> &pi, const std::vector<uint32_t> &pj, DistanceMatrix &distances) const {
     const uint32_t np = (uint32_t)pi.size(), D = (uint32_t)alphabet.DIM;
     Backend &be = default_backend();
@@ -133,7 +142,7 @@ void DistanceFactoryML::computeDistances(const std::vector<int32_t> &counts, con
         m.min_dist = cmdlineopts.min_dist; m.max_dist = cmdlineopts.max_dist; m.indel_rate = cmdlineopts.indel_rate;
         m.mldist = cmdlineopts.mldist_flag ? 1 : 0; m.mldist_gap = cmdlineopts.mldist_gap_flag ? 1 : 0;
         std::vector<double> dist(np), var(np);
-        done = be.mldist_batch(m, np, counts.data(), gaps.data(), seqlen.data(), dist.data(), var.data());
+        done = be.mldist_batch(m, np, counts, gaps, seqlen.data(), dist.data(), var.data());
         if (done)
             for (uint32_t p = 0; p < np; ++p) {
                 distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dist[p];
@@ -150,7 +159,7 @@ void DistanceFactoryML::computeDistances(const std::vector<int32_t> &counts, con
         auto work = [&](unsigned t) {
             std::vector<int32_t> c((size_t)D * D);
             for (uint32_t p = t; p < np; p += nt) {
-                std::copy(counts.begin() + (size_t)p * D * D, counts.begin() + (size_t)(p + 1) * D * D, c.begin());
+                std::copy(counts + (size_t)p * D * D, counts + (size_t)(p + 1) * D * D, c.begin());
                 distvar_t dv = computeDistance(c, gaps[p], seqlen[p]);
                 distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
                 distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
@@ -209,28 +218,40 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
         for (auto &p : pr) { pi.push_back(p.first); pj.push_back(p.second); }
     }
     const uint32_t np = (uint32_t)pi.size();
-    std::vector<int32_t> counts((size_t)np * D * D);
-    std::vector<uint32_t> gaps(np);
     Backend &be = default_backend();
+    // Without --mldist / --mldist_gap the distance of a pair reads (ident, total) of its count matrix and nothing else
+    // (DistanceFactoryML.h:143-146, 175-178): the device reduces them and 8 B per pair come back instead of 4 D^2.
+    const bool reduced = !(cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag);
+    const size_t per = reduced ? 2 : (size_t)D * D;
+    // result buffers in pinned memory (the D2H copies write them directly), not zero-filled: every pair's slice is written by its tile
+    int32_t *counts = (int32_t *)be.host_alloc(std::max<size_t>(sizeof(int32_t) * (size_t)np * per, 16));
+    uint32_t *gaps = (uint32_t *)be.host_alloc(std::max<size_t>(4 * (size_t)np, 16));
     for (uint32_t p = 0; p < np; ++p)
         be.cells_nw += (uint64_t)(offs[pi[p] + 1] - offs[pi[p]]) * (offs[pj[p] + 1] - offs[pj[p]]);
     auto t0 = std::chrono::steady_clock::now();
     {
         const int nw = std::max(1, be.workers());
-        // tile size: four tiles per worker (a tile should fill a device: its persistent grid holds ~7000 pairs at once), at
-        // least 256 pairs; PGM_NW_TILE overrides
-        uint32_t tile = std::max<uint32_t>(256u, (np + 4u * (uint32_t)nw - 1u) / (4u * (uint32_t)nw));
+        // Tile size.  A call costs ~0.3 ms beside its kernel (staging of the inputs, launch, the last D2H: bench.py all_pairs_nw
+        // rank0_fixed_ms_per_call) and a worker hides that of tile k under the kernel of tile k+1 (two tiles in flight), so what
+        // matters is (a) that a tile fills a device — its persistent grid holds 7168 pairs at once; fewer pairs leave CUs idle —
+        // and (b) that the last tiles of the ticket queue are small against a worker's share.  Three tiles per worker, at least
+        // 256 pairs; the pairs are sorted by cost, so the last tiles are also the cheapest.  PGM_NW_TILE overrides.
+        uint32_t tile = std::max<uint32_t>(256u, (np + 3u * (uint32_t)nw - 1u) / (3u * (uint32_t)nw));
         if (const char *e = getenv("PGM_NW_TILE")) tile = (uint32_t)std::max(1, atoi(e));
         const uint32_t ntiles = np ? (np + tile - 1) / tile : 0;
         std::atomic<uint32_t> next_tile(0);
         auto farm = [&](int w) {
+            int pending = -1;
             for (;;) {
                 const uint32_t t = next_tile.fetch_add(1);
                 if (t >= ntiles) break;
                 const uint32_t p0 = t * tile, cnt = std::min(tile, np - p0);
-                be.nw_pairs_batch(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), cnt, pi.data() + p0,
-                                  pj.data() + p0, counts.data() + (size_t)p0 * D * D, gaps.data() + p0, w);
+                const int ticket = be.nw_pairs_submit(D, scoring_matrix_.data(), gap_open, gap_extend, n, syms.data(), offs.data(), cnt, pi.data() + p0,
+                                                      pj.data() + p0, reduced ? 1u : 0u, counts + (size_t)p0 * per, gaps + p0, w);
+                if (pending >= 0) be.nw_pairs_wait(pending, w);
+                pending = ticket;
             }
+            if (pending >= 0) be.nw_pairs_wait(pending, w);
         };
         std::vector<std::thread> devs;
         for (int w = 1; w < nw; ++w) devs.emplace_back(farm, w);
@@ -241,7 +262,17 @@ DistanceMatrix DistanceFactoryAlign::computePwDistances(const std::map<std::stri
     be.seconds_nw += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::vector<double> seqlen(np);
     for (uint32_t p = 0; p < np; ++p) seqlen[p] = ((double)(offs[pi[p] + 1] - offs[pi[p]]) + (double)(offs[pj[p] + 1] - offs[pj[p]])) / 2.0;
-    computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    if (reduced) {
+        for (uint32_t p = 0; p < np; ++p) {
+            const distvar_t dv = computeDistance((double)counts[2 * (size_t)p], (double)counts[2 * (size_t)p + 1], nullptr, gaps[p], seqlen[p]);
+            distances.D(pi[p], pj[p]) = distances.D(pj[p], pi[p]) = dv.dist;
+            distances.V(pi[p], pj[p]) = distances.V(pj[p], pi[p]) = dv.var;
+        }
+    } else {
+        computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    }
+    be.host_free(counts);
+    be.host_free(gaps);
     dump_distances(distances);
     return distances;
 }
@@ -439,7 +470,7 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     }
     std::vector<double> seqlen(np, ((double)L + (double)L) / 2.0);
     const auto tq0 = std::chrono::steady_clock::now();
-    computeDistances(counts, gaps, seqlen, pi, pj, distances);
+    computeDistances(counts.data(), gaps.data(), seqlen, pi, pj, distances);
     if (getenv("PGM_HOST_PROFILE"))
         fprintf(stderr, "  prealigned distances: pair counts %s, estimates %.1f ms\n", done ? "on the device" : "on the host",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());

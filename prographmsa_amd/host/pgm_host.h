@@ -228,9 +228,14 @@ struct Backend {
     virtual void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                                     const pgm_model *const *model, const pgm_scores *scores,
                                     pgm_align_out *out, int worker = 0) = 0;
-    virtual void nw_pairs_batch(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
+    // One tile of alignPair jobs in two halves (include/pgm_hip.h: pgm_nw_pairs_submit / pgm_nw_pairs_wait): a worker keeps two
+    // tiles in flight.  flags & PGM_NW_REDUCED: counts = (ident, total) per pair.  Result buffers come from host_alloc.
+    virtual int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
                                 const int8_t *syms, const uint32_t *offs, uint32_t npairs, const uint32_t *pi,
-                                const uint32_t *pj, int32_t *counts, uint32_t *gaps, int worker = 0) = 0;
+                                const uint32_t *pj, uint32_t flags, int32_t *counts, uint32_t *gaps, int worker = 0) = 0;
+    virtual void nw_pairs_wait(int ticket, int worker = 0) = 0;
+    virtual void *host_alloc(size_t bytes) { return malloc(bytes); }
+    virtual void host_free(void *p) { free(p); }
     // number of device contexts the farms may drive, one host thread each
     virtual int workers() const { return 1; }
     // batched DistanceFactoryML::computeDistance and the pair counts of an alignment on the device;
@@ -377,9 +382,10 @@ class DistanceFactoryML {   // DistanceFactoryML.h
 public:
     DistanceFactoryML(const Alphabet &a, const ModelFactory *mf) : alphabet(a), model_factory(mf) {}
     distvar_t computeDistance(const std::vector<int32_t> &counts, index_t gaps, double seqlen) const;  // :137-190
+    distvar_t computeDistance(double ident, double total, const std::vector<int32_t> *counts, index_t gaps, double seqlen) const;
     // computeDistance of every pair: on the device when PGM_DEVICE_MLDIST is set, the backend has the kernel and the model is
     // in eigen form (20 states), else on host threads; fills the symmetric matrices
-    void computeDistances(const std::vector<int32_t> &counts, const std::vector<uint32_t> &gaps, const std::vector<double> &seqlen,
+    void computeDistances(const int32_t *counts, const uint32_t *gaps, const std::vector<double> &seqlen,
                           const std::vector<uint32_t> &pi, const std::vector<uint32_t> &pj, DistanceMatrix &distances) const;
 protected:
     distvar_t computeMLDist(const std::vector<int32_t> &counts, index_t gaps, double seqlen, double dist0, double var0) const;  // :66-135

@@ -144,7 +144,7 @@ def test_farm_partitions():
     assert sorted(pairs) == farm.all_pairs(len(lengths))
     cost = [lengths[a] * lengths[b] for a, b in pairs]
     assert cost == sorted(cost, reverse=True)
-    assert farm.tile_size(32640, 1) == 8160 and farm.tile_size(32640, 8) == 1020 and farm.tile_size(100, 8) == 256 and farm.tile_size(100, 8, "7") == 7
+    assert farm.tile_size(32640, 1) == 10880 and farm.tile_size(32640, 8) == 1360 and farm.tile_size(100, 8) == 256 and farm.tile_size(100, 8, "7") == 7
     q = farm.TicketQueue("t", 1)
     assert [q.next() for _ in range(4)] == [0, 1, 2, 3]
     for world in (1, 2, 3, 8):

@@ -54,6 +54,66 @@ def test_nw_pairs_bit_exact(ctx, dim):
     assert np.array_equal(gg, go_)
 
 
+def test_nw_two_tiles_in_flight_reduced_and_pinned(ctx):
+    """pgm_nw_pairs_submit / _wait: two tiles in flight on one context (pageable and pinned result buffers), a third submit is
+    refused, PGM_NW_REDUCED returns (trace, sum) of the count matrices; all against the oracle's full matrices."""
+    import oracle_lib
+    import prographmsa_amd as pg
+    rng = np.random.default_rng(77)
+    dim = 20
+    base = rng.integers(0, dim, 700)
+    seqs = []
+    for L in [40, 300, 511, 513, 640, 700, 90, 257, 129, 64]:
+        s_ = base[:L].copy()
+        mut = rng.random(L) < 0.25
+        s_[mut] = rng.integers(0, dim + 1, mut.sum())
+        seqs.append(np.minimum(s_, dim).astype(np.int8))
+    offs = np.concatenate([[0], np.cumsum([len(s_) for s_ in seqs])]).astype(np.uint32)
+    syms = np.concatenate(seqs)
+    pairs = [(i, j) for i in range(len(seqs)) for j in range(i + 1, len(seqs))]
+    score = np.ascontiguousarray(_score(dim, rng), np.int32)
+    co, go_ = oracle_lib.nw_pairs(dim, score, -10, -2, syms, offs, [a for a, _ in pairs], [b for _, b in pairs])
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    half = len(pairs) // 2
+    tiles = [pairs[:half], pairs[half:]]
+    for flags, per in ((0, dim * dim), (pg.PGM_NW_REDUCED, 2)):
+        for pinned in (False, True):
+            bufs, tickets, keep = [], [], []
+            for tl in tiles:
+                pi = np.array([a for a, _ in tl], np.uint32); pj = np.array([b for _, b in tl], np.uint32)
+                if pinned:
+                    cp, gp = pg.lib.pgm_host_alloc(len(tl) * per * 4), pg.lib.pgm_host_alloc(len(tl) * 4)
+                    assert cp and gp
+                    c = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_int32)), (len(tl) * per,)); g = np.ctypeslib.as_array(C.cast(gp, C.POINTER(C.c_uint32)), (len(tl),))
+                    keep.append((cp, gp))
+                else:
+                    c, g = np.full(len(tl) * per, -7, np.int32), np.zeros(len(tl), np.uint32)
+                t = C.c_int(-1)
+                pg.check(pg.lib.pgm_nw_pairs_submit(ctx.handle, dim, P(score, C.c_int32), -10, -2, len(seqs), P(syms, C.c_int8), P(offs, C.c_uint32), len(tl),
+                                                    P(pi, C.c_uint32), P(pj, C.c_uint32), flags, P(c, C.c_int32), P(g, C.c_uint32), C.byref(t)))
+                bufs.append((c, g, pi, pj)); tickets.append(t.value)
+            assert sorted(tickets) == [0, 1]
+            t = C.c_int(-1)
+            c3, g3 = np.zeros(per, np.int32), np.zeros(1, np.uint32)
+            rc = pg.lib.pgm_nw_pairs_submit(ctx.handle, dim, P(score, C.c_int32), -10, -2, len(seqs), P(syms, C.c_int8), P(offs, C.c_uint32), 1,
+                                            P(bufs[0][2], C.c_uint32), P(bufs[0][3], C.c_uint32), flags, P(c3, C.c_int32), P(g3, C.c_uint32), C.byref(t))
+            assert rc == pg.PGM_ERR_INVALID                       # a third tile without a wait
+            for k in (0, 1):
+                pg.check(pg.lib.pgm_nw_pairs_wait(ctx.handle, tickets[k]))
+            assert pg.lib.pgm_nw_pairs_wait(ctx.handle, 0) == pg.PGM_ERR_INVALID   # nothing in flight any more
+            got_c = np.concatenate([b[0] for b in bufs]).reshape(len(pairs), per)
+            got_g = np.concatenate([b[1] for b in bufs])
+            assert np.array_equal(got_g, go_)
+            if flags:
+                cm = co.reshape(len(pairs), dim, dim)
+                assert np.array_equal(got_c[:, 0], np.trace(cm, axis1=1, axis2=2)) and np.array_equal(got_c[:, 1], cm.sum((1, 2)))
+            else:
+                assert np.array_equal(got_c, co)
+            del bufs, got_c, got_g
+            for cp, gp in keep:
+                pg.lib.pgm_host_free(cp); pg.lib.pgm_host_free(gp)
+
+
 def test_nw_empty(ctx):
     c, g = _nw_gpu(ctx, 20, _score(20, np.random.default_rng(0)), -10, -2, np.zeros(4, np.int8), [0, 4], [], [])
     assert c.size == 0 and g.size == 0
