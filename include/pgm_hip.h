@@ -193,7 +193,9 @@ float pgm_csprofile_last_kernel_ms(pgm_ctx *ctx);
  * src/DistanceFactoryML.h:66-190 for a batch of pairs (the tail of computePwDistances, src/DistanceFactoryAlign.h:49-51,
  * and of DistanceFactoryPrealigned, src/DistanceFactoryPrealigned.h:84-88).  The substitution model is handed over in the
  * eigen form the reference builds in ModelFactory (src/ModelFactory.h:48-67): P(d) = V diag(exp(sigma d)) V^-1, all
- * dim x dim matrices column-major double; dim <= 20.  min_dist / max_dist are the clamps of parseDistance
+ * dim x dim matrices column-major double; dim <= 20: the kernel keeps P(d) and its two derivatives of one pair in the registers
+ * of one wavefront (20 x 20 / 64 lanes); the 61-state codon models are refused (PGM_ERR_INVALID) and the host mirror keeps its
+ * estimator for them (host/distance.cpp: 16 host threads; 8128 pairs of config 4 take 0.1 s).  min_dist / max_dist are the clamps of parseDistance
  * (src/ModelFactory.h:125), dist_max / var_max / var_min the constants of DistanceFactoryML.cpp:3-32.
  * counts[p * dim * dim + s1 + dim * s2], gaps[p], seqlen[p] = (L1 + L2) / 2 per pair -> dist[p], var[p]. */
 typedef struct pgm_mldist_model {

@@ -948,7 +948,12 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems));
     if (lean_list.empty()) lean_list.push_back(0u);
-    if (tools_env("PGM_FILL_TRACE") && njobs) (void)hipMalloc((void **)&b->d_trace, 176 * items.size() + 48 * (size_t)njobs);   // 6 words per item + 16 per item for the helper wavefronts, then 6 words per lean job
+    if (tools_env("PGM_FILL_TRACE") && njobs &&   // (tools build) 6 words per item + 16 per item for the helper wavefronts, then 6 words per lean job
+        hipMalloc((void **)&b->d_trace, 176 * items.size() + 48 * (size_t)njobs) != hipSuccess) {
+        b->d_trace = nullptr;
+        pgm_align_batch_destroy(ctx, b);
+        return fail(PGM_ERR_NOMEM, "no device memory for the timeline of PGM_FILL_TRACE");
+    }
     if (items.size() > std::max<size_t>(1, total_bands)) {   // (cannot happen: an item holds at least one band)
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, "work list longer than the number of bands");
