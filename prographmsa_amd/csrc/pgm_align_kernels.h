@@ -470,7 +470,27 @@ struct PgmTbLds {
     uint32_t len;
     int nbig;                                  // cells of the link band whose nodes have 5..8 predecessors (M link by a whole wavefront)
     uint16_t big[128];
+    uint16_t gtab[PGM_LK_W * PGM_LK_TAB] __attribute__((aligned(16)));   // the pre-linked tables of the grid row the walker is in (copy of PgmJob::ltab[grow])
+    uint32_t grow;                             // that row (0xFFFFFFFF: none)
+    uint32_t gnext;                            // 1: the row above it was complete when this one was loaded
 };
+
+// Staging of one grid tile for pgm_prelink_tile: the tile's cells with a halo of PGM_LK_H rows above and columns to the left
+// (predecessor cells), the scores and the predecessor records of the tile's own rows and columns, and the table being built.
+#define PGM_LK_HW (PGM_LK_T + PGM_LK_H)
+struct PgmLkLds {
+    float4 cell[PGM_LK_HW * PGM_LK_HW];        // rows hy0.., columns hx0..
+    float S[PGM_LK_T * PGM_LK_T];
+    uint32_t p_cnt[2 * PGM_LK_T];
+    uint32_t p_c[2 * PGM_LK_T * PGM_TB_PK];
+    float p_v[2 * PGM_LK_T * PGM_TB_PK];
+    uint32_t p_u[2 * PGM_LK_T * PGM_TB_PK];
+    uint16_t tab[PGM_LK_TAB] __attribute__((aligned(16)));
+    int nbig;
+    uint16_t big[PGM_LK_T * PGM_LK_T];
+};
+// A pre-linked successor: bit 15 valid, bits 12..13 next state (0 M, 1 X, 2 Y), bits 6..11 / 0..5 rows / columns back to the next cell.
+__device__ __forceinline__ uint16_t pgm_lk_code(uint32_t st, uint32_t dy, uint32_t dx) { return (uint16_t)(0x8000u | (st << 12) | (dy << 6) | dx); }
 
 // predecessor list of one node: either in the tile (LDS) or in memory
 struct PgmPredView {
@@ -498,9 +518,12 @@ __device__ static void pgm_traceback_publish(const PgmJob &J, const uint32_t len
     }
 }
 
-__device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads, unsigned long long *stat) {
+// lq: the batch's queue of pre-link tasks (pgm_fill_kernel's idle phase): lq[0] tasks announced, lq[1] tracebacks finished, lq_ids[k] = job + 1
+__device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int tid, const int nthreads, unsigned long long *stat,
+                                         int *lq, int *lq_ids, const uint32_t jid) {
     constexpr uint32_t TT = PGM_TB_T;
     const uint32_t n1 = J.n1, n2 = J.n2;
+
     const PgmPred P1 = {J.pp1, J.pc1, J.pv1, J.pu1};
     const PgmPred P2 = {J.pp2, J.pc2, J.pv2, J.pu2};
 
@@ -725,31 +748,63 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             }
         }
     };
+    // (Deciding every visited cell in the walker instead of precomputing links — tried for the MODE 2 jobs, whose paths visit 11
+    // cells per tile: a lone wavefront needs 1.1 us per cell for the two LDS round trips and ~100 dependent instructions of the
+    // fast evaluation below, the root's traceback went from 0.93 to 1.27 ms.  The links stay; the fast evaluation serves the
+    // cells without one.)
+    const bool use_links = true;
+    // the pre-linked tables of grid row T.grow -> LDS, all threads (36 KB: nine 8-byte device-coherent loads each, one round trip);
+    // with them the completion count of the row above, which is where the walker goes next
+    auto load_row = [&]() {
+        const uint32_t gy = T.grow;
+        constexpr uint32_t NW = PGM_LK_W * PGM_LK_TAB * 2u / 8u, NT = 64u * PGM_WAVES;
+        static_assert(NW % NT == 0u, "row table: whole rounds of the workgroup");
+        const PGM_GLOBAL unsigned long long *src = (const PGM_GLOBAL unsigned long long *)(uintptr_t)(J.ltab + (size_t)gy * (PGM_LK_W * PGM_LK_TAB));
+        unsigned long long v[NW / NT];
+#pragma unroll
+        for (uint32_t q = 0; q < NW / NT; ++q) v[q] = __hip_atomic_load(src + (uint32_t)tid + NT * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t nx = 0u;
+        if (tid == 64 && gy != 0u) nx = (uint32_t)__hip_atomic_load(J.lready + (gy - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= min(J.lcols, PGM_LK_W) ? 1u : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < NW / NT; ++q) ((unsigned long long *)T.gtab)[(uint32_t)tid + NT * q] = v[q];
+        if (tid == 64) T.gnext = nx;
+    };
     if (tid == 0) {
+        T.grow = 0xFFFFFFFFu; T.gnext = 0u;
+        if (J.lrows != 0u) __hip_atomic_store(J.lready + J.lrows + 1, (int)(J.lrows - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         T.ty0 = n1 - 2 >= TT - 1 ? n1 - 2 - (TT - 1) : 0u;
         T.tx0 = n2 - 2 >= TT - 1 ? n2 - 2 - (TT - 1) : 0u;
         T.ay = n1 - 2; T.ax = n2 - 2;
         T.req = 1;
+        if (J.lrows != 0u && lq) {   // idle workers may start on this job's corridor now
+            const int slot = __hip_atomic_fetch_add(lq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(lq_ids + slot, (int)(jid + 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     stage();
     __syncthreads();
-    links();
-    __syncthreads();
-    links_big();
-    __syncthreads();
+    if (use_links) {
+        links();
+        __syncthreads();
+        links_big();
+        __syncthreads();
+    }
 
     if (loader) {
         // ---- loaders (wavefronts 1..): serve the walker's tile requests ----
         for (;;) {
             __syncthreads();            // request posted
             if (T.req == 2) break;
+            if (T.req == 3) { load_row(); __syncthreads(); continue; }
             stage();
             __syncthreads();            // cells, scores, predecessor lists staged
-            links();
-            __syncthreads();            // successor table complete but for the cells of links_big
-            links_big();
-            __syncthreads();
+            if (use_links) {
+                links();
+                __syncthreads();        // successor table complete but for the cells of links_big
+                links_big();
+                __syncthreads();
+            }
         }
     } else {
         // ---- walker: wavefront 0, uniform control flow; the one-off END step is evaluated by lane 0 alone ----
@@ -851,8 +906,11 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         // graphs are 1 node back; in merged graphs most skip edges span a few nodes (farther ones are read from memory)
         const uint32_t margin = J.has_extras ? 4u : 1u;
         uint32_t guard = 0;
-        unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0, st_stage = 0;
+        unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0, st_stage = 0, st_grid = 0;
         bool score_stale = false;
+        uint32_t nl_y = 0xFFFFFFFFu, nl_x = 0xFFFFFFFFu;   // last cell at which the pre-linked tables had nothing to follow
+        uint32_t grow = 0xFFFFFFFFu;                       // grid row whose tables are in LDS
+        bool gnext = false;
         while ((x != 0 || y != 0) && status == PGM_OK) {
             if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
             // the walker state is the same in all lanes: keep it in scalar registers so that the branches below are scalar
@@ -860,8 +918,60 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             current_state = __builtin_amdgcn_readfirstlane(current_state);
             // new tile when the walker is near the low edge of the current one (or outside it, after a far edge)
             const int offb = ((int)(y - ty0) - (int)(x - tx0)) - adiag;
-            if (((y - ty0) >= TT || ((y - ty0) < margin && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < margin && tx0 != 0)) ||
-                ((offb < -band || offb > band) && (y != ay || x != ax))) {
+            const bool reload = ((y - ty0) >= TT || ((y - ty0) < margin && ty0 != 0)) || ((x - tx0) >= TT || ((x - tx0) < margin && tx0 != 0)) ||
+                                (use_links && (offb < -band || offb > band) && (y != ay || x != ax));
+            // Before staging a tile of its own the walker looks whether idle workers have pre-linked the grid tile it stands in
+            // (pgm_prelink_tile): it then copies that tile's table (6 KB) and follows its links from grid tile to grid tile — one
+            // flag and one table round trip per tile, no staging, no link pass — until it meets a cell without a link or a tile
+            // that is not ready, and goes on there as before.
+            if (reload && J.lrows != 0u && !(y == nl_y && x == nl_x)) {
+                bool moved = false;
+                uint32_t st = (uint32_t)(current_state == State_m ? 0 : (current_state == State_x ? 1 : 2));
+                const uint32_t gw = min(J.lcols, PGM_LK_W);
+                for (;;) {
+                    const uint32_t gy = y >> 5;
+                    if (gy >= J.lrows) break;
+                    const uint32_t first = pgm_lk_first(n1, n2, J.lcols, gy);
+                    if ((x >> 5) - first >= gw) break;                      // outside the corridor
+                    if (grow != gy) {
+                        // the row's tables: complete?  (known from the look-ahead of the previous row's load, else one flag round trip)
+                        bool ready = gy + 1u == grow && gnext;
+                        if (!ready) ready = (uint32_t)__hip_atomic_load(J.lready + gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gw;
+                        if (!ready) break;
+                        if (lane == 0) {
+                            T.grow = gy; T.req = 3;
+                            __hip_atomic_store(J.lready + J.lrows + 1, (int)gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rows above gy are still wanted
+                        }
+                        __syncthreads();        // request posted
+                        load_row();
+                        __syncthreads();
+                        grow = gy; gnext = T.gnext != 0u;
+                    }
+                    bool left_row = false;
+                    for (;;) {
+                        const uint32_t j = (x >> 5) - first;
+                        if (j >= gw) break;
+                        const uint32_t code = T.gtab[j * PGM_LK_TAB + st * (TT * TT) + (y & 31u) * TT + (x & 31u)];
+                        if (!(code & 0x8000u)) break;
+                        y -= (code >> 6) & 63u; x -= code & 63u; st = (code >> 12) & 3u;
+                        moved = true;
+                        if ((y | x) == 0u) break;
+                        if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = st == 1u ? 0xFFFFFFFFu : y; mo.m2[mo.len] = st == 2u ? 0xFFFFFFFFu : x; }
+                        ++mo.len;
+                        if ((y >> 5) != gy) { left_row = true; break; }
+                    }
+                    y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x); st = __builtin_amdgcn_readfirstlane(st);
+                    if (!left_row) break;
+                }
+                if (moved) {
+                    current_state = st == 0u ? State_m : (st == 1u ? State_x : State_y);
+                    score_stale = true;
+                    ++st_grid;
+                    continue;
+                }
+                nl_y = y; nl_x = x;   // nothing to follow from here: decide this cell the usual way, then look again
+            }
+            if (reload) {
                 ty0 = y >= TT - 1 ? y - (TT - 1) : 0u;
                 tx0 = x >= TT - 1 ? x - (TT - 1) : 0u;
                 const unsigned long long r0 = stat ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -871,10 +981,12 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 stage();
                 __syncthreads();        // cells, scores, predecessor lists staged
                 if (stat) st_stage += __builtin_amdgcn_s_memrealtime() - r0;
-                links();
-                __syncthreads();        // successor table complete but for the cells of links_big
-                links_big();
-                __syncthreads();
+                if (use_links) {
+                    links();
+                    __syncthreads();    // successor table complete but for the cells of links_big
+                    links_big();
+                    __syncthreads();
+                }
                 if (stat) { st_reload += __builtin_amdgcn_s_memrealtime() - r0; ++st_nreload; }
             }
             // fast path: follow the precomputed links.  A link's low 12 bits are the table index of the next (state, cell),
@@ -899,6 +1011,62 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     current_state = st == 0u ? State_m : (st == 1u ? State_x : State_y);
                     score_stale = true;
                     continue;
+                }
+            }
+            // fast evaluation: the candidates of the current (cell, state) one per lane in PredIterator order (state M: lane = 8 ky
+            // + kx; gap states: lane = 2 k + (0 extension | 1 opening)), every operand from the staged tile: two LDS round trips and
+            // one ballot per path node.  Anything else — a list longer than the tile's records, a candidate cell outside the tile,
+            // no candidate that recomputes the stored value exactly, a repeat edge, an inconsistent source — is left to the
+            // general code below, which decides the same cell again from scratch.
+            if (in_tile(y, x)) {
+                const uint32_t ly = y - ty0, lx = x - tx0, ci = ly * TT + lx;
+                const uint32_t cy = T.p_cnt[ly], cx = T.p_cnt[TT + lx];
+                const bool in_m = current_state == State_m, in_y = current_state == State_y;
+                if ((in_m || in_y ? cy - 1u < (uint32_t)PGM_TB_PK : true) && (in_m || !in_y ? cx - 1u < (uint32_t)PGM_TB_PK : true)) {
+                    const float4 c0 = T.cell[ci];
+                    const float S0 = T.S[ci];
+                    const uint32_t ka = in_m ? (uint32_t)lane >> 3 : (uint32_t)lane >> 1, kb = in_m ? (uint32_t)lane & 7u : (uint32_t)lane & 1u;
+                    const bool valid = in_m ? (ka < cy && kb < cx) : (ka < (in_y ? cy : cx));
+                    const uint32_t yi = ly * PGM_TB_PK + (ka & 7u), xi = (TT + lx) * PGM_TB_PK + ((in_m ? kb : ka) & 7u);
+                    uint32_t yp = y, xp = x, uu = 0u;
+                    float yv = 0.0f, xv = 0.0f;
+                    if (in_m || in_y) { yp = T.p_c[yi]; yv = T.p_v[yi]; uu |= T.p_u[yi]; }
+                    if (in_m || !in_y) { xp = T.p_c[xi]; xv = T.p_v[xi]; uu |= T.p_u[xi]; }
+                    const bool inside = yp >= ty0 && xp >= tx0;
+                    if (__builtin_amdgcn_ballot_w64(valid && !inside) == 0ull) {
+                        const float4 c = T.cell[valid ? (yp - ty0) * TT + (xp - tx0) : ci];
+                        float d;
+                        if (in_m) d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S0), yv), xv)));
+                        else if (in_y) d = fabsf(__fsub_rn(c0.w, __fsub_rn(__fadd_rn(kb == 0u ? c.w : c.z, kb == 0u ? s.gap_extend : s.gap_init), yv)));
+                        else d = fabsf(__fsub_rn(c0.y, __fsub_rn(__fadd_rn(kb == 0u ? c.y : c.z, kb == 0u ? s.gap_extend : s.gap_init), xv)));
+                        const unsigned long long zero = __builtin_amdgcn_ballot_w64(valid && d == 0.0f);
+                        if (zero != 0ull) {
+                            const int win = __ffsll((long long)zero) - 1;
+                            const uint32_t w_yp = rl_u(yp, win), w_xp = rl_u(xp, win), w_rep = rl_u(uu, win), w_kind = rl_u(kb, win);
+                            const float wz = rl_f(c.z, win), wm = rl_f(c.x, win), wx = rl_f(c.y, win), wy = rl_f(c.w, win);
+                            int next_state = current_state;
+                            bool ok = w_rep == 0u;
+                            if ((in_m || w_kind == 1u) && (w_yp | w_xp) != 0u) {   // a W source: its state by equality in the order M, Y, X
+                                if (wz == wm) next_state = State_m;
+                                else if (wz == wy) next_state = State_y;
+                                else if (wz == wx) next_state = State_x;
+                                else ok = false;
+                            }
+                            if (ok) {
+                                y = w_yp; x = w_xp;
+                                current_state = next_state;
+                                score_stale = true;
+                                if (x != 0 || y != 0) {
+                                    if (lane == 0 && mo.len < mo.cap) {
+                                        mo.m1[mo.len] = current_state == State_x ? 0xFFFFFFFFu : y;
+                                        mo.m2[mo.len] = current_state == State_y ? 0xFFFFFFFFu : x;
+                                    }
+                                    ++mo.len;
+                                }
+                                continue;
+                            }
+                        }
+                    }
                 }
             }
             ++st_slow;
@@ -1002,7 +1170,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             J.result->status = status;
             T.len = mo.len;
             T.req = 2;
-            if (stat) { stat[0] = (st_stage << 32) | st_reload; stat[1] = (st_nreload << 32) | st_slow; }
+            if (stat) { stat[0] = (st_stage << 32) | st_reload; stat[1] = (st_nreload << 32) | ((st_grid & 0xffffull) << 16) | (st_slow & 0xffffull); }
         }
         __syncthreads();                // "request" that ends the loaders' loop
     }
@@ -1010,6 +1178,188 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
     __threadfence_block();
     __syncthreads();
     pgm_traceback_publish(J, T.len, tid, nthreads);
+    if (tid == 0 && lq) {
+        if (J.lrows != 0u) __hip_atomic_store(J.lready + J.lrows, (int)(J.lrows * PGM_LK_W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no tile of this job is wanted any more
+        __hip_atomic_fetch_add(lq + (PGM_SY_TB_DONE - PGM_SY_LQ_N), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// One grid tile of a job's corridor, all threads of a worker that has no band to sweep (pgm_fill_kernel's idle phase): the
+// successor of every (cell, state) of the tile, decided as the walker of pgm_traceback_job decides it — same candidates in
+// PredIterator order, same strict comparisons, W sources resolved by equality in the order M, Y, X — from the tile's cells
+// plus a halo of PGM_LK_H rows / columns.  No link where the walker's general code has to look: a predecessor beyond the
+// halo, more than PGM_TB_PK predecessors, a repeat edge, an inconsistent source.  The job is complete (its traceback has
+// started), so every cell read here is final.
+__device__ static void pgm_prelink_tile(const PgmJob &J, PgmLkLds &G, const uint32_t k, const int tid) {
+    constexpr uint32_t TT = PGM_LK_T, HW = PGM_LK_HW, NT = 64u * PGM_WAVES, PK = PGM_TB_PK;
+    const uint32_t n1 = J.n1, n2 = J.n2;
+    const uint32_t w = min(J.lcols, PGM_LK_W), r = k / PGM_LK_W, jj = k % PGM_LK_W;
+    if (jj >= w || r >= J.lrows) return;
+    const uint32_t gx = pgm_lk_first(n1, n2, J.lcols, r) + jj;
+    const uint32_t cy0 = TT * r, cx0 = TT * gx;
+    const uint32_t hy0 = cy0 >= PGM_LK_H ? cy0 - PGM_LK_H : 0u, hx0 = cx0 >= PGM_LK_H ? cx0 - PGM_LK_H : 0u;
+    const pgm_scores sc = J.sc;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // cells written by other XCDs
+    __syncthreads();                                     // (the previous tile's table has been copied out)
+    {
+        // cells in anti-diagonal order (one anti-diagonal of the region is one contiguous run of the cell storage, see stage())
+        constexpr int NC = (int)((HW * HW + NT - 1) / NT);
+        float4 cv[NC];
+        uint32_t cslot[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const uint32_t i = min((uint32_t)tid + NT * u, HW * HW - 1u);
+            const uint32_t half = HW * (HW + 1u) / 2u;
+            const bool up = i < half;
+            const uint32_t m = up ? i : HW * HW - 1u - i;
+            uint32_t d = (uint32_t)((sqrtf(8.0f * (float)m + 1.0f) - 1.0f) * 0.5f);
+            while (d * (d + 1u) / 2u > m) --d;
+            while ((d + 1u) * (d + 2u) / 2u <= m) ++d;
+            const uint32_t kk = m - d * (d + 1u) / 2u;
+            const uint32_t ly = up ? kk : HW - 1u - kk, lx = up ? d - kk : HW - 1u - (d - kk);
+            cslot[u] = ly * HW + lx;
+            cv[u] = J.cells[pgm_cell_index(J, min(hy0 + ly, n1 - 2), min(hx0 + lx, n2 - 2))];
+        }
+        float sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = (uint32_t)tid + NT * u;
+            sv[u] = pgm_emission_at(J, min(cy0 + i / TT, n1 - 2), min(cx0 + i % TT, n2 - 2));
+        }
+        const uint32_t slot = (uint32_t)tid / PK, kk = (uint32_t)tid % PK;
+        const bool row = slot < TT;
+        const uint32_t v = row ? cy0 + slot : cx0 + (slot - TT);
+        const PgmTbNode *rec = (row ? J.tb1 : J.tb2) + min(v, (row ? n1 : n2) - 1);
+        const uint32_t cnt = rec->cnt, ec = rec->c[kk], eu = rec->u[kk];
+        const float ev = rec->v[kk];
+#pragma unroll
+        for (int u = 0; u < NC; ++u)
+            if ((uint32_t)tid + NT * u < HW * HW) G.cell[cslot[u]] = cv[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) G.S[(uint32_t)tid + NT * u] = sv[u];
+        if (kk == 0) G.p_cnt[slot] = v < (row ? n1 : n2) ? cnt : 0xFFFFFFFFu;
+        G.p_c[tid] = ec; G.p_v[tid] = ev; G.p_u[tid] = eu;
+        if (tid == 0) G.nbig = 0;
+    }
+    __syncthreads();
+    auto hc = [&](uint32_t yy, uint32_t xx) { return min((yy - hy0) * HW + (xx - hx0), HW * HW - 1u); };
+    auto pick = [&](const float4 &c, uint32_t y, uint32_t x, uint32_t yp, uint32_t xp) -> uint16_t {
+        uint32_t st;
+        if ((yp | xp) == 0u) st = 0u;
+        else if (c.z == c.x) st = 0u;
+        else if (c.z == c.w) st = 2u;
+        else if (c.z == c.y) st = 1u;
+        else return (uint16_t)0;
+        return pgm_lk_code(st, y - yp, x - xp);
+    };
+    for (uint32_t task = (uint32_t)tid; task < PGM_LK_TAB; task += NT) {
+        const uint32_t st_task = task / (TT * TT), ci = task % (TT * TT), ly = ci / TT, lx = ci % TT, y = cy0 + ly, x = cx0 + lx;
+        uint16_t link = 0;
+        if (y + 1 < n1 && x + 1 < n2 && (y | x) != 0u) {
+            const float4 c0 = G.cell[hc(y, x)];
+            const uint32_t cy = G.p_cnt[ly], cx = G.p_cnt[TT + lx];
+            if (st_task == 0u && cy - 1u < PK && cx - 1u < PK && c0.x > PGM_NEG_INF) {
+                if (cy > PGM_TB_LK || cx > PGM_TB_LK) {   // 5..8 predecessors: a wavefront per cell (below)
+                    const int slot = __hip_atomic_fetch_add(&G.nbig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    G.big[slot] = (uint16_t)ci;
+                } else {
+                    const float S = G.S[ci];
+                    uint32_t yp[PGM_TB_LK], xp[PGM_TB_LK];
+                    float yv[PGM_TB_LK], xv[PGM_TB_LK];
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < PGM_TB_LK; ++q) {
+                        yp[q] = G.p_c[ly * PK + q]; yv[q] = G.p_v[ly * PK + q];
+                        xp[q] = G.p_c[(TT + lx) * PK + q]; xv[q] = G.p_v[(TT + lx) * PK + q];
+                        ok = ok && ((uint32_t)q >= cy || yp[q] >= hy0) && ((uint32_t)q >= cx || xp[q] >= hx0);
+                    }
+                    float wz[PGM_TB_LK][PGM_TB_LK];
+#pragma unroll
+                    for (int ky = 0; ky < PGM_TB_LK; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < PGM_TB_LK; ++kx) wz[ky][kx] = G.cell[hc(yp[ky], xp[kx])].z;
+                    float best = INFINITY;
+                    uint32_t wy = 0, wx = 0, wky = 0, wkx = 0;
+#pragma unroll
+                    for (int ky = 0; ky < PGM_TB_LK; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < PGM_TB_LK; ++kx) {
+                            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(wz[ky][kx], S), yv[ky]), xv[kx])));
+                            if ((uint32_t)ky < cy && (uint32_t)kx < cx && best > d) { best = d; wy = yp[ky]; wx = xp[kx]; wky = ky; wkx = kx; }
+                        }
+                    if (ok && best < INFINITY && (G.p_u[ly * PK + wky] | G.p_u[(TT + lx) * PK + wkx]) == 0u) link = pick(G.cell[hc(wy, wx)], y, x, wy, wx);
+                }
+            }
+            if (st_task == 2u && cy - 1u < PK && c0.w > PGM_NEG_INF) {   // state Y: row predecessors, extension before opening
+                float best = INFINITY;
+                bool ok = true, rep_edge = false, open = false;
+                uint32_t wy = 0;
+                float4 wc = c0;
+                for (uint32_t q = 0; q < cy; ++q) {
+                    const uint32_t yp = G.p_c[ly * PK + q];
+                    if (yp < hy0) { ok = false; break; }
+                    const float yv = G.p_v[ly * PK + q];
+                    const float4 c = G.cell[hc(yp, x)];
+                    const bool ru = G.p_u[ly * PK + q] != 0u;
+                    float d = fabsf(__fsub_rn(c0.w, __fsub_rn(__fadd_rn(c.w, sc.gap_extend), yv)));
+                    if (best > d) { best = d; wy = yp; wc = c; rep_edge = ru; open = false; }
+                    d = fabsf(__fsub_rn(c0.w, __fsub_rn(__fadd_rn(c.z, sc.gap_init), yv)));
+                    if (best > d) { best = d; wy = yp; wc = c; rep_edge = ru; open = true; }
+                }
+                if (ok && best < INFINITY && !rep_edge) link = open ? pick(wc, y, x, wy, x) : pgm_lk_code(2u, y - wy, 0u);
+            }
+            if (st_task == 1u && cx - 1u < PK && c0.y > PGM_NEG_INF) {   // state X: column predecessors
+                float best = INFINITY;
+                bool ok = true, rep_edge = false, open = false;
+                uint32_t wx = 0;
+                float4 wc = c0;
+                for (uint32_t q = 0; q < cx; ++q) {
+                    const uint32_t xp = G.p_c[(TT + lx) * PK + q];
+                    if (xp < hx0) { ok = false; break; }
+                    const float xv = G.p_v[(TT + lx) * PK + q];
+                    const float4 c = G.cell[hc(y, xp)];
+                    const bool ru = G.p_u[(TT + lx) * PK + q] != 0u;
+                    float d = fabsf(__fsub_rn(c0.y, __fsub_rn(__fadd_rn(c.y, sc.gap_extend), xv)));
+                    if (best > d) { best = d; wx = xp; wc = c; rep_edge = ru; open = false; }
+                    d = fabsf(__fsub_rn(c0.y, __fsub_rn(__fadd_rn(c.z, sc.gap_init), xv)));
+                    if (best > d) { best = d; wx = xp; wc = c; rep_edge = ru; open = true; }
+                }
+                if (ok && best < INFINITY && !rep_edge) link = open ? pick(wc, y, x, y, wx) : pgm_lk_code(1u, 0u, x - wx);
+            }
+        }
+        G.tab[task] = link;
+    }
+    __syncthreads();
+    {   // M links of the cells whose nodes have 5..8 predecessors: one wavefront per cell, lane = 8 ky + kx (PredIterator order)
+        const int wave = tid >> 6, lane_b = tid & 63;
+        const int nbig = G.nbig;
+        for (int i = wave; i < nbig; i += PGM_WAVES) {
+            const uint32_t ci = G.big[i], ly = ci / TT, lx = ci % TT, y = cy0 + ly, x = cx0 + lx;
+            const uint32_t cy = G.p_cnt[ly], cx = G.p_cnt[TT + lx];
+            const uint32_t ky = (uint32_t)lane_b >> 3, kx = (uint32_t)lane_b & 7u;
+            const bool valid = ky < cy && kx < cx;
+            const uint32_t yp = G.p_c[ly * PK + ky], xp = G.p_c[(TT + lx) * PK + kx];
+            const float yv = G.p_v[ly * PK + ky], xv = G.p_v[(TT + lx) * PK + kx];
+            const uint32_t rep = G.p_u[ly * PK + ky] | G.p_u[(TT + lx) * PK + kx];
+            const bool inside = yp >= hy0 && xp >= hx0;
+            if (__builtin_amdgcn_ballot_w64(valid && !inside) != 0ull) continue;
+            const float4 c0 = G.cell[hc(y, x)];
+            const float S = G.S[ci];
+            const float4 c = G.cell[(valid && inside) ? hc(yp, xp) : hc(y, x)];
+            const float d = fabsf(__fsub_rn(c0.x, __fsub_rn(__fsub_rn(__fadd_rn(c.z, S), yv), xv)));
+            const unsigned long long zero = __builtin_amdgcn_ballot_w64(valid && d == 0.0f);
+            if (zero == 0ull) continue;   // (no exact candidate: the walker searches the minimum itself)
+            const int win = __ffsll((long long)zero) - 1;
+            if (lane_b == win && rep == 0u) G.tab[ci] = pick(c, y, x, yp, xp);
+        }
+    }
+    __syncthreads();
+    // the table -> memory, then the flag
+    uint16_t *dst = J.ltab + (size_t)k * PGM_LK_TAB;
+    for (uint32_t i = (uint32_t)tid; i < PGM_LK_TAB * 2u / 16u; i += NT) ((uint4 *)dst)[i] = ((const uint4 *)G.tab)[i];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(J.lready + r, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // tiles of grid row r complete
 }
 
 #define PGM_SPIN_LIMIT (1u << 24)
@@ -2324,12 +2674,11 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
                                                       uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_) {
     const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
     if (!DBG) trace = nullptr;
-    int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list
-    // LDS of the band sweeps (one slot per sweeping wavefront); the traceback a worker runs after a job's last band reuses it
-    __shared__ __attribute__((aligned(16))) union { uint8_t pool[PGM_POOL]; PgmTbLds t; } L;
-    __shared__ int item_lds, tb_go;
+    int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list, [2] lean list; the traceback kernel's words from [32] on (PGM_SY_*)
+    // LDS of the band sweeps (one slot per sweeping wavefront)
+    __shared__ __attribute__((aligned(16))) struct { uint8_t pool[PGM_POOL]; } L;
+    __shared__ int item_lds;
     __shared__ __attribute__((aligned(16))) int fsync[12];   // MODE 2 item: [0] last recorded step + 2, [1..7] steps published by helper wavefront h, [8] row entry list built
-    static_assert(sizeof(PgmTbLds) <= PGM_POOL, "traceback tile does not fit the worker's LDS");
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // role is wave-uniform: keep its branches scalar
     bool aborted = false;
     for (;;) {
@@ -2386,20 +2735,83 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
         }
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         if (last_band) {
-            // The last band of a job is the last one to finish, and every cell of the job is written through to memory
-            // by now: this worker walks the traceback (all its wavefronts, whatever they did in this item).
+            // The last band of a job is the last one to finish.  Its traceback is not this kernel's business (the walker's code in
+            // here cost the sweeps 40 VGPRs, and a worker that walks for 0.6 ms sweeps nothing): pgm_tb_kernel follows on the stream.
+            // Only an aborted batch leaves its records here.
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-                if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-                tb_go = ok ? 1 : 0;
+            if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            __syncthreads();
-            if (tb_go != 0 && !NOTRACEBACK) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop cached lines of cells other XCDs have written since
-                pgm_traceback_job(J, L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tracebacks of the jobs pgm_fill_kernel has swept, and the pre-linking that makes the long ones short.  The kernel follows the
+// fill kernel on its stream (every cell is final and visible); one worker of 512 threads per CU.  A worker takes jobs from the
+// list — largest first: its walk is the longest — until there is none left; from then on it pre-links grid tiles of the
+// corridors of the tracebacks still under way (pgm_prelink_tile), in the order their walkers will reach them, and leaves when
+// the last traceback has finished.  After the root of a guide tree, one job on one worker, everybody else pre-links: the
+// serial stage-link-walk of that traceback becomes one table load per grid row.
+// (Tried first: this kernel BESIDE the fill kernel on a third stream, fed through a queue by the workers that complete a job's
+// last band.  Its idle workers have to wait for CUs, and with its grid pending behind the fill kernel's for milliseconds the
+// sweeps stopped making progress in one launch of a few hundred — until this kernel's workers ran into their poll limit a
+// minute later.  Not understood, not shipped.)
+template <bool DBG>
+__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob *__restrict__ jobs, const int2 *__restrict__ list, uint32_t ntb, int *__restrict__ sync,
+                                                                unsigned long long *__restrict__ trace, uint32_t spin_limit, uint32_t lq_off) {
+    if (!DBG) trace = nullptr;
+    __shared__ __attribute__((aligned(16))) union { PgmTbLds t; PgmLkLds g; } L;
+    __shared__ int cmd_lds, arg_lds;
+    int *abort_flag = sync, *lq = sync + PGM_SY_LQ_N, *lq_ids = sync + lq_off;
+    bool walking = true;   // there may be a job left in the list
+    uint32_t lk_backoff = 0u;
+    for (uint32_t polls = 0; polls < (spin_limit ? spin_limit : PGM_SPIN_LIMIT); ++polls) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cmd = -2;   // -3: traceback of list entry arg; >= 0: pre-link tile cmd of job arg; -2: nothing right now; -1: leave
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                (uint32_t)__hip_atomic_load(sync + PGM_SY_TB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntb) cmd = -1;
+            else if (walking) {
+                const uint32_t k = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_TBQ_N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k < ntb) { cmd = -3; arg_lds = (int)k; } else cmd = -5;
+            } else if ((polls & ((1u << lk_backoff) - 1u)) == 0u) {
+                // pre-link: the newest announcements first (their walkers have the longest way to go), at most eight looked at
+                // per poll; the grid rows the walker has left are skipped in one step
+                const uint32_t na = (uint32_t)__hip_atomic_load(lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t looked = 0;
+                for (uint32_t t = na; t-- > 0u && looked < 8u && cmd == -2;) {
+                    const int id = __hip_atomic_load(lq_ids + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (id == 0) continue;       // announced, not written yet
+                    ++looked;
+                    const PgmJob &Jq = jobs[id - 1];
+                    const uint32_t ntiles = Jq.lrows * PGM_LK_W;
+                    int *next = Jq.lready + Jq.lrows;
+                    const uint32_t cur = (uint32_t)__hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur >= ntiles) continue;
+                    // tiles are handed out from the END corner back (ticket k -> tile ntiles - 1 - k)
+                    const uint32_t wrow = (uint32_t)__hip_atomic_load(next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t skip_to = ntiles - min(ntiles, (wrow + 1u) * PGM_LK_W);
+                    if (cur < skip_to) __hip_atomic_fetch_max(next, (int)skip_to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t k = (uint32_t)__hip_atomic_fetch_add(next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k < ntiles && k >= skip_to) { cmd = (int)(ntiles - 1u - k); arg_lds = id - 1; }
+                }
             }
+            cmd_lds = cmd;
+        }
+        __syncthreads();
+        const int cmd = cmd_lds;
+        if (cmd == -1) break;
+        if (cmd == -5) { walking = false; continue; }
+        if (cmd == -2) { lk_backoff = min(lk_backoff + 1u, 3u); __builtin_amdgcn_s_sleep(127); continue; }   // ~3 us; the announcements are looked at every 2, 4, 8 polls while they have nothing
+        lk_backoff = 0u;
+        if (cmd == -3) {
+            const int2 e = list[arg_lds];   // (job, its last item of the work list: the timeline's slot)
+            const int it = e.y;
+            pgm_traceback_job(jobs[e.x], L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr, lq, lq_ids, (uint32_t)e.x);
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
+        } else {
+            pgm_prelink_tile(jobs[arg_lds], L.g, (uint32_t)cmd, (int)threadIdx.x);
         }
     }
 }

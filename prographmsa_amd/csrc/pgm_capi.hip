@@ -157,6 +157,8 @@ struct pgm_align_batch {
     PgmItem *d_items = nullptr;       // band list of the batch (fill work queue)
     uint32_t *d_lean = nullptr;       // the lean jobs (pgm_lean_kernel's work queue), largest first
     uint32_t nlean = 0, nlean_workers = 0;
+    uint32_t lq_off = 0, ntb = 0, ntb_workers = 0;   // pre-link announcements inside d_sync; jobs of the general path (one traceback each); workers of pgm_tb_kernel
+    int2 *d_tblist = nullptr;         // those jobs, largest first: (job, its last item of the work list)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // stream -> stream2 after the emission kernel, stream2 -> stream after the lean kernel
     unsigned long long *d_trace = nullptr;   // PGM_FILL_TRACE=file: per-item timeline, written by fetch (tools only)
     uint32_t test_spin_limit = 0, test_stall_job = 0xFFFFFFFFu, test_stall_band = 0;   // pgm_align_batch_test_stall
@@ -417,8 +419,8 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
 
 // Device-only regions of one job (offsets inside the batch's work / cell / result / score buffers) and its slice of the
 // progress counters (pass 1 of pgm_align_batch_create).
-struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog, codes, endcell; };
-struct BatchLayout { DevLayout W, C, O, SL; size_t sync_ints = 4; };   // sync: [0] abort flag, [1] ticket counter of the band list (+ padding to 16 B)
+struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog, codes, endcell, ltab, lready; uint32_t lrows, lcols; };
+struct BatchLayout { DevLayout W, C, O, SL; size_t sync_ints = 64; };   // sync: [0] abort flag, [1] ticket counter of the band list, [2] of the lean list; on a cache line of their own, [32] pre-link tasks announced, [33] tracebacks finished (polled by every idle worker)
 static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, uint32_t rshift, bool lean, bool keep, JobOff &o) {
     const uint32_t R = 1u << rshift, rows = PGM_ROWS * R;
     const uint32_t dp = dim <= 20 ? 20 : 64, nb = (n1 - 1 + rows - 1) / rows, tsteps = (n2 - 1) + 63;
@@ -440,6 +442,16 @@ static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, u
     o.S = L.SL.take(sizeof(float) * (size_t)nb * nblk * 64u * PGM_BLOCK * R, 1024);
     o.prog = L.sync_ints;
     L.sync_ints += (nb + 3) / 4 * 4;
+    // pre-linked traceback tiles (PgmJob::ltab): the long jobs of the general path (from PGM_LK_MIN_ROWS rows: the ones whose
+    // tracebacks end a batch; pre-linking every job of the headline batch — 26 000 tiles — cost the sweeps still running 30 %)
+    o.lrows = (!lean && n1 - 1 >= PGM_LK_MIN_ROWS && n2 - 1 >= 4 * PGM_LK_T) ? (n1 - 1 + PGM_LK_T - 1) / PGM_LK_T : 0u;
+#ifdef PGM_NO_PRELINK   /* A/B builds only: same kernels, no pre-linking */
+    o.lrows = 0u;
+#endif
+    o.lcols = (n2 - 1 + PGM_LK_T - 1) / PGM_LK_T;
+    o.ltab = L.W.take(std::max<size_t>((size_t)o.lrows * PGM_LK_W * PGM_LK_TAB * 2, 16), 256);
+    o.lready = L.sync_ints;                              // tiles complete per grid row, then the claim counter and the walker's row (zeroed with the progress counters)
+    L.sync_ints += ((size_t)o.lrows + 2 + 3) / 4 * 4;
 }
 // A plain chain 0 -> 1 -> ... -> n-1 with finite edge costs and no repeat edges (a sequence graph).  Decided before the layout
 // pass because jobs of two such graphs get the lean sweep's storage (R rows per lane, code bytes, matrices only on request);
@@ -552,6 +564,7 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
     const uint32_t dbg_flags = tools_env("PGM_TEST_NOSTORE") ? (uint32_t)atoi(tools_env("PGM_TEST_NOSTORE")) : 0u;   // (tools build)
     const bool fork = b->nlean != 0;
+    const bool tbk = b->nitems != 0 && b->ntb != 0 && dbgv != 8 && !tools_env("PGM_NO_TBK");   // the traceback kernel behind the fill kernel (PGM_NO_TBK, tools build: the sweeps alone, every result stays pending)
     if (fork && ((e = hipEventRecord(b->ev_fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess)) return e;
     if (b->nitems == 0) {}   // (a batch of lean jobs only)
     else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
@@ -568,8 +581,14 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
 #endif
         hipLaunchKernelGGL((pgm_lean_kernel<2>), dim3(b->nlean_workers), dim3(64 * PGM_WAVES), 0, ctx->stream2, b->d_jobs, b->d_lean, b->nlean, b->d_sync, tr2, spin_limit);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipEventRecord(b->ev_join, ctx->stream2)) != hipSuccess || (e = hipStreamWaitEvent(s, b->ev_join, 0)) != hipSuccess) return e;
     }
+    if (tbk) {
+        // the traceback kernel, behind the fill kernel on its stream: one worker per CU the lean kernel does not hold
+        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off);
+        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (fork && ((e = hipEventRecord(b->ev_join, ctx->stream2)) != hipSuccess || (e = hipStreamWaitEvent(s, b->ev_join, 0)) != hipSuccess)) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
     return hipSuccess;
@@ -645,6 +664,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     b->cell_bytes = std::max<size_t>(L.C.bytes, 16);
     b->out_bytes = std::max<size_t>(L.O.bytes, 16);
     b->s_bytes = std::max<size_t>(L.SL.bytes, 16);
+    b->lq_off = (uint32_t)L.sync_ints;                   // ids of the jobs whose tracebacks have started (pre-link announcements)
+    L.sync_ints += ((size_t)njobs + 3) / 4 * 4;
     const size_t sync_ints = L.sync_ints;
     b->sync_ints = sync_ints;
     hipError_t alloc_err = hipSuccess, alloc_host_err = hipSuccess;
@@ -659,7 +680,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     DevLayout SM;
     const size_t small_sync = SM.take(sync_ints * sizeof(int)), small_jobs = SM.take(sizeof(PgmJob) * std::max(1u, njobs)),
                  small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)),
-                 small_lean = SM.take(4 * (size_t)std::max(1u, njobs));
+                 small_lean = SM.take(4 * (size_t)std::max(1u, njobs)), small_tblist = SM.take(8 * (size_t)std::max(1u, njobs));
     const size_t small_bytes = SM.bytes;
     std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
     std::atomic<int> upload_err((int)hipSuccess);
@@ -678,6 +699,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
             b->d_order = (uint32_t *)(b->d_small + small_order);
             b->d_items = (PgmItem *)(b->d_small + small_items);
             b->d_lean = (uint32_t *)(b->d_small + small_lean);
+            b->d_tblist = (int2 *)(b->d_small + small_tblist);
         }
         alloc_err = e2;
         alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
@@ -843,6 +865,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         J.endcell = (float4 *)(w + o.endcell);
         J.S = (float *)(b->d_S + o.S);
         J.prog = b->d_sync + o.prog;
+        J.ltab = (uint16_t *)(w + o.ltab); J.lready = b->d_sync + o.lready; J.lrows = o.lrows; J.lcols = o.lcols;
     }
     b->order.resize(njobs);
     std::iota(b->order.begin(), b->order.end(), 0u);
@@ -890,7 +913,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
                 const bool last = band + cnt == J.nb;
                 Item it;
                 it.rem = tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb;
-                it.dur = tau * ((double)(cnt - 1) * lag + J.tsteps) + (last ? tb : 0.0);
+                it.dur = tau * ((double)(cnt - 1) * lag + J.tsteps);   // (the traceback is another kernel's: pgm_tb_kernel)
+                (void)last;
                 it.gap = tau * (double)cnt * lag;                 // the next item may start this long after this one
                 it.job = i; it.band = band; it.count = cnt;
                 per_job[i].push_back(it);
@@ -958,7 +982,17 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, "work list longer than the number of bands");
     }
+    std::vector<int2> tblist;
+    {
+        std::vector<int> last_item(njobs, 0);
+        for (size_t k = 0; k < items.size(); ++k) if (items[k].band + items[k].count == b->jobs[items[k].job].nb) last_item[items[k].job] = (int)k;
+        for (uint32_t q = 0; q < njobs; ++q) { const uint32_t i = b->order[q]; if (!b->jobs[i].lean) tblist.push_back(make_int2((int)i, last_item[i])); }
+        b->ntb = (uint32_t)tblist.size();
+        b->ntb_workers = std::max(1u, std::min((uint32_t)std::max(1, ctx->prop.multiProcessorCount) - b->nlean_workers, std::max(b->ntb * 8u, 64u)));
+        if (tblist.empty()) tblist.push_back(make_int2(0, 0));
+    }
     if ((e = (hipError_t)upload_err.load()) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_tblist, tblist.data(), 8 * tblist.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_jobs, b->jobs.data(), sizeof(PgmJob) * njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
@@ -1059,6 +1093,22 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
         else (void)hipGetLastError();
     }
     const int aborted = *b->h_flag;
+#ifdef PGM_TOOLS
+    if (aborted || tools_env("PGM_DUMP_SYNC")) {   // the counters of the launch, for a post-mortem
+        std::vector<int> sy(b->sync_ints);
+        (void)hipMemcpy(sy.data(), b->d_sync, 4 * b->sync_ints, hipMemcpyDeviceToHost);
+        fprintf(stderr, "sync: abort %d ticket %d lean %d | lq_n %d tb_done %d tb ticket %d | nitems %u nworkers %u nlean %u lean_workers %u ntb %u\n", sy[0], sy[1], sy[2],
+                sy[PGM_SY_LQ_N], sy[PGM_SY_TB_DONE], sy[PGM_SY_TBQ_N], b->nitems, b->nworkers, b->nlean, b->nlean_workers, b->ntb);
+        for (uint32_t i = 0; i < b->njobs; ++i) {
+            const PgmJob &J = b->jobs[i];
+            if (J.lean) continue;
+            const int *pr = sy.data() + (J.prog - b->d_sync);
+            bool done = true;
+            for (uint32_t q = 0; q < J.nb; ++q) done = done && pr[q] >= (int)J.tsteps;
+            if (!done) { fprintf(stderr, "  job %u (%u x %u, mode2 %u, %u bands): prog", i, J.n1, J.n2, J.mode2, J.nb); for (uint32_t q = 0; q < J.nb; ++q) fprintf(stderr, " %d", pr[q]); fprintf(stderr, " (of %u)\n", J.tsteps); }
+        }
+    }
+#endif
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list

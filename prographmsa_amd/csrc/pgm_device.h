@@ -145,6 +145,16 @@ struct PgmJob {
     float4 *endcell;
     uint32_t keep_cells;
 
+    // Pre-linked traceback tiles (pgm_prelink_tile): workers with nothing else to do build, for the 32 x 32 tiles of a fixed
+    // grid that lie within PGM_LK_W / 2 tiles of the matrix diagonal, the successor of every (cell, state) — decided exactly as
+    // the walker would — while the job's traceback worker is already walking.  ltab[tile k][state][32 ly + lx] is a 16-bit link
+    // (pgm_lk_*); lready[r] = tiles of grid row r whose tables are complete and visible, lready[lrows] the next tile to take,
+    // lready[lrows + 1] the grid row the walker is in (rows above it are still wanted).
+    // Tile k = r * PGM_LK_W + j: grid row r (rows 32 r ..), grid column pgm_lk_first(r) + j.  lrows = 0: none (lean / small jobs).
+    uint16_t *ltab;
+    int *lready;
+    uint32_t lrows, lcols; // grid rows, grid columns of the whole matrix
+
     // DP storage
     float4 *cells;         // [nb][tsteps][R][64]
     int *prog;             // [nb] steps of band b that are complete and visible device-wide (zeroed before every launch)
@@ -160,6 +170,24 @@ struct PgmJob {
     Result *hresult;
 };
 
+
+// words of the batch's sync block the traceback kernel polls (a cache line of their own; [0] abort flag, [1] / [2] the tickets of the band and lean lists)
+#define PGM_SY_LQ_N 32      // tracebacks that have started (pre-link announcements, ids in lq_ids)
+#define PGM_SY_TB_DONE 33   // tracebacks finished
+#define PGM_SY_TBQ_N 34     // ticket counter of the traceback kernel's job list
+#define PGM_LK_W 6u        // grid tiles per grid row in the corridor around the diagonal (paths of the headline batch stay within 40 columns of it)
+#define PGM_LK_T 32u       // tile edge
+#define PGM_LK_MIN_ROWS 1216u   // jobs with fewer rows are not pre-linked (19 bands: the MODE 2 threshold)
+#define PGM_LK_H 16u       // halo above / left of a tile staged with it: predecessors up to this far outside the tile still get a link
+#define PGM_LK_TAB (3u * PGM_LK_T * PGM_LK_T)   // links per tile
+// first grid column of the corridor in grid row r
+__host__ __device__ inline uint32_t pgm_lk_first(uint32_t n1, uint32_t n2, uint32_t lcols, uint32_t r) {
+    const uint32_t w = lcols < PGM_LK_W ? lcols : PGM_LK_W;
+    const uint64_t xc = ((uint64_t)(PGM_LK_T * r + PGM_LK_T / 2u) * (n2 - 1u)) / (n1 - 1u);   // column of the diagonal at the tile row's middle
+    const uint32_t g = (uint32_t)(xc / PGM_LK_T);
+    const uint32_t lo = g >= w / 2u ? g - w / 2u : 0u;
+    return lo + w > lcols ? lcols - w : lo;
+}
 
 // One unit of fill work: `count` consecutive bands (64 rows each) of job `job`, starting at `band`, one per wavefront of
 // the worker that takes the item (count <= PgmJob::nslots <= 8; a MODE 2 job: one band, swept with seven helper wavefronts).  The list is ordered so that a job's bands come in
