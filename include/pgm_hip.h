@@ -129,6 +129,10 @@ int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_p
  * last reset, and their number: the stage times of exactly the steps a caller timed (bench.py), not of extra launches. */
 int pgm_align_batch_stage_times(pgm_align_batch *b, int reset, float *ms_prep, float *ms_emission, float *ms_fill,
                                 uint32_t *launches);
+/* Timeline of the last completed launch: ticks[2 i] = the moment job i's last band was complete, ticks[2 i + 1] = the moment
+ * its traceback was published, both in 10 ns ticks of the device's real-time counter (differences are meaningful, the origin
+ * is not).  Tells which job's chain of sweeps, or which traceback, a batch waits for (tools/probe_jobtimes.py). */
+int pgm_align_batch_job_times(pgm_ctx *ctx, pgm_align_batch *b, uint64_t *ticks);
 /* Test hook for the hand-off time-out path: in the following launches band `band` of job `job` never publishes its progress
  * and a wavefront that waits for another gives up after `spin_limit` polls (0: the default); the band below then times out,
  * raises the batch's abort flag and every unfinished job reports PGM_ERR_DEVICE.  job = 0xFFFFFFFF switches it off. */

@@ -2671,7 +2671,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 template <bool NOTRACEBACK, bool DBG>
 __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace,
-                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_) {
+                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_, uint32_t ticket_off) {
     const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
     if (!DBG) trace = nullptr;
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list, [2] lean list; the traceback kernel's words from [32] on (PGM_SY_*)
@@ -2687,7 +2687,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
         if (threadIdx.x == 0) {
             int it = -1;
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                it = __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                it = __hip_atomic_fetch_add(sync + ticket_off, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ([1], or [PGM_SY_CRIT_TICKET]: the launch of the batch's longest chains)
             item_lds = (it >= 0 && (uint32_t)it < nitems) ? it : -1;
             for (int k = 0; k < 12; ++k) fsync[k] = 0;
         }
@@ -2739,9 +2739,48 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             // here cost the sweeps 40 VGPRs, and a worker that walks for 0.6 ms sweeps nothing): pgm_tb_kernel follows on the stream.
             // Only an aborted batch leaves its records here.
             __syncthreads();
+            if (threadIdx.x == 0) J.times[0] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The bands of the jobs that need no helper wavefronts (MODE 0 / 1: one wavefront sweeps one band on its own), scheduled per
+// WAVEFRONT.  In pgm_fill_kernel a worker's eight wavefronts take eight consecutive bands of one job together and meet again
+// when the last of them is through: band k of the item starts 78 k steps after band 0 and ends as much later, so for the
+// 1000-column jobs of the lower tree levels a third of the worker's wavefront-time is ramp, and a job of 17 bands leaves a
+// worker with ONE busy wavefront for its last item.  Here every wavefront of a worker takes its own next band from the list
+// (ordered by the host like the items: longest remaining path first, a job's bands ascending) and sweeps it in its own
+// eighth of the CU's LDS; nothing in a MODE 0 / 1 sweep involves another wavefront.  Runs beside pgm_fill_kernel (which keeps
+// the MODE 2 jobs) and pgm_lean_kernel on a stream of its own, on its share of the CUs; pgm_tb_kernel follows all three.
+__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_band_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ bands, uint32_t nbands,
+                                                                  int *__restrict__ sync, uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band) {
+    __shared__ __attribute__((aligned(16))) uint8_t pool[PGM_POOL];
+    int *abort_flag = sync;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint8_t *slot = pool + (size_t)role * (PGM_POOL / PGM_WAVES / 16 * 16);
+    bool aborted = false;
+    for (;;) {
+        // every lane takes part in the dequeue (lane 0 adds 1, the others 0), see pgm_nw_kernel
+        uint32_t q = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_BAND_TICKET, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        if (q >= nbands || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        const PgmItem item = bands[q];
+        {   // s_setprio takes an immediate
+            const uint32_t pr = __builtin_amdgcn_readfirstlane(item.prio);
+            if (pr >= 3u) __builtin_amdgcn_s_setprio(3); else if (pr == 2u) __builtin_amdgcn_s_setprio(2); else if (pr == 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+        const PgmJob &J = jobs[item.job];
+        const uint32_t b = item.band;
+        const bool stall = item.job == stall_job && b == stall_band;
+        if (J.has_extras) pgm_sweep_band<1, false>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, nullptr, nullptr, 0u);
+        else pgm_sweep_band<0, false>(J, b, slot, lane, abort_flag, aborted, spin_limit, stall, nullptr, nullptr, 0u);
+        if (b + 1u == J.nb && lane == 0) J.times[0] = __builtin_amdgcn_s_memrealtime();
+        if (b + 1u == J.nb && lane == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // an aborted batch leaves its records here
+            J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -2758,14 +2797,16 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
 // sweeps stopped making progress in one launch of a few hundred — until this kernel's workers ran into their poll limit a
 // minute later.  Not understood, not shipped.)
 template <bool DBG>
-__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob *__restrict__ jobs, const int2 *__restrict__ list, uint32_t ntb, int *__restrict__ sync,
-                                                                unsigned long long *__restrict__ trace, uint32_t spin_limit, uint32_t lq_off) {
+__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob *__restrict__ jobs, const int2 *__restrict__ list, uint32_t ntb, int *__restrict__ sync_,
+                                                                unsigned long long *__restrict__ trace, uint32_t spin_limit, uint32_t lq_off, uint32_t sybase) {
     if (!DBG) trace = nullptr;
     __shared__ __attribute__((aligned(16))) union { PgmTbLds t; PgmLkLds g; } L;
     __shared__ int cmd_lds, arg_lds;
-    int *abort_flag = sync, *lq = sync + PGM_SY_LQ_N, *lq_ids = sync + lq_off;
+    // (a batch has up to two instances of this kernel — behind pgm_band_kernel and behind pgm_fill_kernel — each with its own
+    // list, counters (sybase) and announcements)
+    int *abort_flag = sync_, *sync = sync_ + sybase, *lq = sync + PGM_SY_LQ_N, *lq_ids = sync_ + lq_off;
     bool walking = true;   // there may be a job left in the list
-    uint32_t lk_backoff = 0u;
+    uint32_t lk_backoff = 0u, lk_first = 0u;   // (thread 0: first announcement that may still have tiles)
     for (uint32_t polls = 0; polls < (spin_limit ? spin_limit : PGM_SPIN_LIMIT); ++polls) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -2776,11 +2817,11 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob 
                 const uint32_t k = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_TBQ_N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (k < ntb) { cmd = -3; arg_lds = (int)k; } else cmd = -5;
             } else if ((polls & ((1u << lk_backoff) - 1u)) == 0u) {
-                // pre-link: the newest announcements first (their walkers have the longest way to go), at most eight looked at
-                // per poll; the grid rows the walker has left are skipped in one step
+                // pre-link: the first announcements first (the jobs are taken largest first, so these are the longest walks), at most
+                // eight with tiles left looked at per poll; the grid rows a walker has left are skipped in one step
                 const uint32_t na = (uint32_t)__hip_atomic_load(lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t looked = 0;
-                for (uint32_t t = na; t-- > 0u && looked < 8u && cmd == -2;) {
+                for (uint32_t t = lk_first; t < na && looked < 8u && cmd == -2; ++t) {
                     const int id = __hip_atomic_load(lq_ids + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     if (id == 0) continue;       // announced, not written yet
                     ++looked;
@@ -2788,7 +2829,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob 
                     const uint32_t ntiles = Jq.lrows * PGM_LK_W;
                     int *next = Jq.lready + Jq.lrows;
                     const uint32_t cur = (uint32_t)__hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cur >= ntiles) continue;
+                    if (cur >= ntiles) { if (t == lk_first) ++lk_first; --looked; continue; }   // (nothing left there, for good)
                     // tiles are handed out from the END corner back (ticket k -> tile ntiles - 1 - k)
                     const uint32_t wrow = (uint32_t)__hip_atomic_load(next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t skip_to = ntiles - min(ntiles, (wrow + 1u) * PGM_LK_W);
@@ -2809,6 +2850,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob 
             const int2 e = list[arg_lds];   // (job, its last item of the work list: the timeline's slot)
             const int it = e.y;
             pgm_traceback_job(jobs[e.x], L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr, lq, lq_ids, (uint32_t)e.x);
+            if (threadIdx.x == 0) jobs[e.x].times[1] = __builtin_amdgcn_s_memrealtime();
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         } else {
             pgm_prelink_tile(jobs[arg_lds], L.g, (uint32_t)cmd, (int)threadIdx.x);
@@ -2853,6 +2895,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 2) pgm_lean_kernel(const PgmJo
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
         if (threadIdx.x == 0) {
+            J.times[0] = __builtin_amdgcn_s_memrealtime();
             const bool ok = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
             if (!ok) { J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
             tb_go = ok ? 1 : 0;
@@ -2862,6 +2905,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 2) pgm_lean_kernel(const PgmJo
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (trace && threadIdx.x == 0) trace[6 * it + 5] = __builtin_amdgcn_s_memrealtime();   // (the walker's statistics are relative to this)
             pgm_traceback_chain<R>(J, pool, &tb_len, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr);
+            if (threadIdx.x == 0) J.times[1] = __builtin_amdgcn_s_memrealtime();
         }
         if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
     }

@@ -50,6 +50,8 @@ struct pgm_ctx {
     int nw_per_cu = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
+    hipStream_t stream3 = nullptr;   // ... and so does the band kernel (pgm_band_kernel)
+    hipStream_t stream4 = nullptr;   // ... and the fill kernel's launch for the longest chains
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
     // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
     enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SMALL, C_SLOTS };   // C_HOST, C_HIN: pinned host memory; C_SMALL: the batch's counters, job descriptors, work list
@@ -157,6 +159,13 @@ struct pgm_align_batch {
     PgmItem *d_items = nullptr;       // band list of the batch (fill work queue)
     uint32_t *d_lean = nullptr;       // the lean jobs (pgm_lean_kernel's work queue), largest first
     uint32_t nlean = 0, nlean_workers = 0;
+    uint32_t nbands = 0, nband_workers = 0;   // pgm_band_kernel: bands of the MODE 0 / 1 jobs, one per wavefront; its workers (CUs)
+    PgmItem *d_bands = nullptr;
+    unsigned long long *d_times = nullptr;   // per job {last band complete, traceback published}, then the launch's start (ticks of 10 ns)
+    hipEvent_t ev_join_b = nullptr;
+    uint32_t ncrit = 0, ncrit_workers = 0, ntb_c = 0;   // the first ncrit items of the work list: the jobs with the longest chains, swept by a launch of their own on their own CUs; their tracebacks
+    hipEvent_t ev_join_c = nullptr;
+    uint32_t ntb_b = 0, ntb_b_workers = 0;          // ... of the jobs pgm_band_kernel sweeps: their instance of pgm_tb_kernel follows it on its stream
     uint32_t lq_off = 0, ntb = 0, ntb_workers = 0;   // pre-link announcements inside d_sync; jobs of the general path (one traceback each); workers of pgm_tb_kernel
     int2 *d_tblist = nullptr;         // those jobs, largest first: (job, its last item of the work list)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // stream -> stream2 after the emission kernel, stream2 -> stream after the lean kernel
@@ -200,6 +209,8 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     HIPCHK(hipGetDeviceProperties(&c->prop, device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
     hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -231,6 +242,8 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     for (int k = 0; k < 2; ++k) if (ctx->sc_ev[k]) (void)hipEventDestroy(ctx->sc_ev[k]);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
         if (ctx->cache_ptr[k]) slot_free(k, ctx->cache_ptr[k]);
+    if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -564,12 +577,19 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     // does not merge the helpers' terms, 4 = no helpers, 8 = no history records
     const uint32_t dbg_flags = tools_env("PGM_TEST_NOSTORE") ? (uint32_t)atoi(tools_env("PGM_TEST_NOSTORE")) : 0u;   // (tools build)
     const bool fork = b->nlean != 0;
-    const bool tbk = b->nitems != 0 && b->ntb != 0 && dbgv != 8 && !tools_env("PGM_NO_TBK");   // the traceback kernel behind the fill kernel (PGM_NO_TBK, tools build: the sweeps alone, every result stays pending)
-    if (fork && ((e = hipEventRecord(b->ev_fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess)) return e;
-    if (b->nitems == 0) {}   // (a batch of lean jobs only)
-    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
-    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items, b->nitems, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags);
+    const bool bandk = b->nbands != 0;
+    const bool tbk = (b->nitems != 0 || bandk) && (b->ntb + b->ntb_c + b->ntb_b) != 0 && dbgv != 8 && !tools_env("PGM_NO_TBK");   // the traceback kernel behind the fill kernel (PGM_NO_TBK, tools build: the sweeps alone, every result stays pending)
+    const bool critk = b->ncrit != 0;
+    if ((fork || bandk || critk) && (e = hipEventRecord(b->ev_fork, s)) != hipSuccess) return e;
+    if (critk && (e = hipStreamWaitEvent(ctx->stream4, b->ev_fork, 0)) != hipSuccess) return e;
+    if (fork && (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess) return e;
+    if (bandk && (e = hipStreamWaitEvent(ctx->stream3, b->ev_fork, 0)) != hipSuccess) return e;
+    const uint32_t nrest = b->nitems - b->ncrit;
+    if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET);
+    if (nrest == 0) {}   // (no job for this launch)
+    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
+    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (fork) {
         // the lean jobs' kernel, launched after the fill kernel (whose grid leaves nlean_workers CUs free)
@@ -582,12 +602,33 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
         hipLaunchKernelGGL((pgm_lean_kernel<2>), dim3(b->nlean_workers), dim3(64 * PGM_WAVES), 0, ctx->stream2, b->d_jobs, b->d_lean, b->nlean, b->d_sync, tr2, spin_limit);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (tbk) {
-        // the traceback kernel, behind the fill kernel on its stream: one worker per CU the lean kernel does not hold
-        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off);
-        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off);
+    const uint32_t njp = (b->njobs + 3u) / 4u * 4u;
+    if (bandk) {
+        // the bands of the MODE 0 / 1 jobs, one per wavefront, on their share of the CUs; their tracebacks follow on the same
+        // stream and the same CUs (the band queue is done well before the chains of the fill kernel are)
+        hipLaunchKernelGGL(pgm_band_kernel, dim3(b->nband_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_bands, b->nbands, b->d_sync, spin_limit, stall_job, stall_band);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (tbk && b->ntb_b) {
+            hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_b_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_tblist + b->ntb + b->ntb_c, b->ntb_b, b->d_sync, b->d_trace, spin_limit, b->lq_off + njp, 8u);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if ((e = hipEventRecord(b->ev_join_b, ctx->stream3)) != hipSuccess) return e;
+    }
+    if (critk) {
+        if (tbk && b->ntb_c) {
+            hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist + b->ntb, b->ntb_c, b->d_sync, b->d_trace, spin_limit, b->lq_off + 2 * njp, 16u);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if ((e = hipEventRecord(b->ev_join_c, ctx->stream4)) != hipSuccess) return e;
+    }
+    if (tbk && b->ntb) {
+        // the tracebacks of the fill kernel's jobs, behind it on its stream
+        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off, 0u);
+        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (bandk && (e = hipStreamWaitEvent(s, b->ev_join_b, 0)) != hipSuccess) return e;
+    if (critk && (e = hipStreamWaitEvent(s, b->ev_join_c, 0)) != hipSuccess) return e;
     if (fork && ((e = hipEventRecord(b->ev_join, ctx->stream2)) != hipSuccess || (e = hipStreamWaitEvent(s, b->ev_join, 0)) != hipSuccess)) return e;
     if (timed && (e = hipEventRecord(b->ev[3], s)) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[4], s)) != hipSuccess) return e;
@@ -665,7 +706,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     b->out_bytes = std::max<size_t>(L.O.bytes, 16);
     b->s_bytes = std::max<size_t>(L.SL.bytes, 16);
     b->lq_off = (uint32_t)L.sync_ints;                   // ids of the jobs whose tracebacks have started (pre-link announcements)
-    L.sync_ints += ((size_t)njobs + 3) / 4 * 4;
+    L.sync_ints += 3 * (((size_t)njobs + 3) / 4 * 4);  // (one array per instance of pgm_tb_kernel)
     const size_t sync_ints = L.sync_ints;
     b->sync_ints = sync_ints;
     hipError_t alloc_err = hipSuccess, alloc_host_err = hipSuccess;
@@ -680,7 +721,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     DevLayout SM;
     const size_t small_sync = SM.take(sync_ints * sizeof(int)), small_jobs = SM.take(sizeof(PgmJob) * std::max(1u, njobs)),
                  small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)),
-                 small_lean = SM.take(4 * (size_t)std::max(1u, njobs)), small_tblist = SM.take(8 * (size_t)std::max(1u, njobs));
+                 small_lean = SM.take(4 * (size_t)std::max(1u, njobs)), small_tblist = SM.take(8 * (size_t)std::max(1u, njobs)),
+                 small_bands = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)), small_times = SM.take(16 * (size_t)std::max(1u, njobs) + 16);
     const size_t small_bytes = SM.bytes;
     std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
     std::atomic<int> upload_err((int)hipSuccess);
@@ -700,6 +742,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
             b->d_items = (PgmItem *)(b->d_small + small_items);
             b->d_lean = (uint32_t *)(b->d_small + small_lean);
             b->d_tblist = (int2 *)(b->d_small + small_tblist);
+            b->d_bands = (PgmItem *)(b->d_small + small_bands);
+            b->d_times = (unsigned long long *)(b->d_small + small_times);
         }
         alloc_err = e2;
         alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
@@ -866,6 +910,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         J.S = (float *)(b->d_S + o.S);
         J.prog = b->d_sync + o.prog;
         J.ltab = (uint16_t *)(w + o.ltab); J.lready = b->d_sync + o.lready; J.lrows = o.lrows; J.lcols = o.lcols;
+        J.times = b->d_times + 2 * (size_t)i;
     }
     b->order.resize(njobs);
     std::iota(b->order.begin(), b->order.end(), 0u);
@@ -887,90 +932,149 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     // persistent workers: one workgroup of 8 wavefronts per CU (it owns the CU's LDS for its sweeps' histories)
     if (const char *env_c = tools_env("PGM_FILL_WORKERS"))   // tools build only
         capacity = std::min<uint32_t>((uint32_t)ctx->prop.multiProcessorCount, (uint32_t)std::max(1, atoi(env_c)));
+    std::vector<PgmItem> bands;   // pgm_band_kernel's list: one band per entry
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
-        std::vector<std::vector<Item>> per_job(njobs);
+        std::vector<std::vector<Item>> per_job(njobs), per_job_b(njobs), per_job_c(njobs);
+        std::vector<double> chain_of(njobs, 0.0);   // chain of sweeps of the jobs of the fill kernel
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = tools_env(k); return v ? atof(v) : d; };   // tools build only
         const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
         const double tau_l = envd("PGM_SIM_TAU_L", 0.27);   // lean sweep: us per step of R rows per lane
-        size_t total = 0;
-        double rmax = 1.0;
+        // The jobs without helper wavefronts go to pgm_band_kernel, band by band (not with the timeline of the tools build, whose
+        // slots are the fill kernel's items, and not a job whose sweep would not fit an eighth of the LDS)
+        const bool use_bands = !tools_env("PGM_FILL_TRACE") && !tools_env("PGM_NO_BANDK");
+        size_t total = 0, total_b = 0;
+        double rmax = 1.0, rsweep = 1.0;   // longest remaining path with / without the traceback behind it
         for (uint32_t q = 0; q < njobs; ++q) {
             const uint32_t i = b->order[q];   // (largest first: the order of the lean queue)
             const PgmJob &J = b->jobs[i];
             const double tau = J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c);     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
-            const uint32_t group = J.nslots;                     // bands per item, one per wavefront of the worker
             if (J.lean) {   // pgm_lean_kernel's queue: a worker's wavefronts cycle over the job's bands (72 steps behind each other), then the walk
                 const double rounds = std::ceil((double)J.nb / PGM_WAVES), first = std::min<double>(J.nb, PGM_WAVES);
                 lean_cost += tau_l * (rounds * J.tsteps + (first - 1.0) * 72.0) + 0.04 * (double)(J.n1 + J.n2);
                 lean_list.push_back(i);
                 continue;
             }
+            const bool per_band = use_bands && !J.mode2 && J.slot_bytes <= (uint32_t)(PGM_POOL / PGM_WAVES / 16 * 16);
+            if (!per_band) chain_of[i] = tau * ((double)(J.nb - 1) * lag + J.tsteps);
+            const uint32_t group = per_band ? 1u : J.nslots;       // bands per item, one per wavefront of the worker
             for (uint32_t band = 0; band < J.nb; band += group) {
                 const uint32_t cnt = std::min(group, J.nb - band);
-                const bool last = band + cnt == J.nb;
                 Item it;
                 it.rem = tau * ((double)(J.nb - 1 - band) * lag + J.tsteps) + tb;
                 it.dur = tau * ((double)(cnt - 1) * lag + J.tsteps);   // (the traceback is another kernel's: pgm_tb_kernel)
-                (void)last;
                 it.gap = tau * (double)cnt * lag;                 // the next item may start this long after this one
                 it.job = i; it.band = band; it.count = cnt;
-                per_job[i].push_back(it);
+                (per_band ? per_job_b : per_job)[i].push_back(it);
                 rmax = std::max(rmax, it.rem);
+                rsweep = std::max(rsweep, it.rem - tb);
             }
             total += per_job[i].size();
+            total_b += per_job_b[i].size();
         }
-        // The CUs are split between the two kernels (one worker per CU in either):
-        for (uint32_t i = 0; i < njobs; ++i) for (const Item &it : per_job[i]) other_cost += it.dur;
-        uint32_t lean_cus = 0;
+        // The CUs are split between the kernels (one worker per CU in each).  All three are waited for before the tracebacks start,
+        // so the time to beat is the longer of the longest chain of sweeps (rsweep) and the whole queue over all CUs: the lean
+        // queue gets the fewest CUs with which it is done within 0.75 of that, the band queue (eight bands at a time per CU) the
+        // fewest with which its simulated schedule ends within 0.9 of it, the fill kernel — one band of a MODE 2 job per CU, the
+        // chains that bound the batch — the rest.
+        double band_cost = 0.0;
+        for (uint32_t i = 0; i < njobs; ++i) { for (const Item &it : per_job[i]) other_cost += it.dur; for (const Item &it : per_job_b[i]) band_cost += it.dur / PGM_WAVES; }
+        const double t_goal = std::max(rsweep, (lean_cost + other_cost + band_cost) / std::max(1u, capacity));
+        uint32_t lean_cus = 0, band_cus = 0;
         if (!lean_list.empty()) {
-            // the fill kernel's time is the longer of its critical path (rmax) and its queue over its workers; the lean queue
-            // gets the fewest CUs with which it is done within 0.7 of that
             lean_cus = capacity;
-            if (total != 0) {
+            if (total + total_b != 0) {
                 const uint32_t lo = std::min(4u, capacity - 1u);
                 for (lean_cus = lo; lean_cus + 4u < capacity; ++lean_cus)
-                    if (lean_cost / lean_cus <= 0.7 * std::max(rmax, other_cost / (double)(capacity - lean_cus))) break;
+                    if (lean_cost / lean_cus <= 0.75 * std::max(t_goal, (other_cost + band_cost) / (double)(capacity - lean_cus))) break;
             }
-            if (const char *v = tools_env("PGM_LEAN_CUS")) lean_cus = std::max(1u, std::min(capacity - (total != 0 ? 1u : 0u), (uint32_t)atoi(v)));
+            if (const char *v = tools_env("PGM_LEAN_CUS")) lean_cus = std::max(1u, std::min(capacity - (total + total_b != 0 ? 1u : 0u), (uint32_t)atoi(v)));
             lean_cus = std::min<uint32_t>(lean_cus, (uint32_t)lean_list.size());
         }
         b->nlean = (uint32_t)lean_list.size();
         b->nlean_workers = lean_cus;
-        if (total != 0) capacity = std::max(1u, capacity - lean_cus);
+        if (total + total_b != 0) capacity = std::max(1u, capacity - lean_cus);
         // event simulation: free workers (min-heap of times), ready items (max-heap of remaining paths), pending successors
-        typedef std::pair<double, uint32_t> TE;   // (time, job)
-        std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
-        for (uint32_t w = 0; w < std::max(1u, capacity); ++w) free_at.push(0.0);
-        std::priority_queue<TE> ready;                                               // (rem, job): next item of that job
-        std::priority_queue<TE, std::vector<TE>, std::greater<TE>> pending;         // (ready time, job)
-        std::vector<uint32_t> next(njobs, 0);
-        for (uint32_t i = 0; i < njobs; ++i) if (!per_job[i].empty()) ready.push({per_job[i][0].rem, i});
-        items.reserve(total);
-        double now = 0.0;
-        while (items.size() < total) {
-            now = std::max(now, free_at.top());
-            while (!pending.empty() && pending.top().first <= now) {
-                const uint32_t j = pending.top().second; pending.pop();
-                ready.push({per_job[j][next[j]].rem, j});
+        auto simulate = [&](std::vector<std::vector<Item>> &pj, size_t count, uint32_t workers, std::vector<PgmItem> &out) -> double {
+            out.clear();
+            double end = 0.0;
+            typedef std::pair<double, uint32_t> TE;   // (time, job)
+            std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+            for (uint32_t w = 0; w < std::max(1u, workers); ++w) free_at.push(0.0);
+            std::priority_queue<TE> ready;                                               // (rem, job): next item of that job
+            std::priority_queue<TE, std::vector<TE>, std::greater<TE>> pending;         // (ready time, job)
+            std::vector<uint32_t> next(njobs, 0);
+            for (uint32_t i = 0; i < njobs; ++i) if (!pj[i].empty()) ready.push({pj[i][0].rem, i});
+            out.reserve(count);
+            double now = 0.0;
+            while (out.size() < count) {
+                now = std::max(now, free_at.top());
+                while (!pending.empty() && pending.top().first <= now) {
+                    const uint32_t j = pending.top().second; pending.pop();
+                    ready.push({pj[j][next[j]].rem, j});
+                }
+                if (ready.empty()) { now = pending.top().first; continue; }              // every free worker would have to wait
+                const uint32_t j = ready.top().second; ready.pop();
+                const Item &it = pj[j][next[j]];
+                // wave priority (s_setprio): the longest paths of the batch win the issue arbitration on their SIMDs
+                out.push_back(PgmItem{it.job, it.band, it.rem > 0.6 * rmax ? 3u : (it.rem > 0.35 * rmax ? 2u : (it.rem > 0.2 * rmax ? 1u : 0u)), it.count});
+                free_at.pop();
+                free_at.push(now + it.dur);
+                end = std::max(end, now + it.dur);
+                // the longest paths of the batch are not held back: their next band gets a worker at once (it spins until the
+                // predecessor is far enough, but then follows it without any queueing delay)
+                if (++next[j] < pj[j].size()) pending.push({pj[j][next[j]].rem > eager * rmax ? now : now + it.gap, j});
             }
-            if (ready.empty()) { now = pending.top().first; continue; }              // every free worker would have to wait
-            const uint32_t j = ready.top().second; ready.pop();
-            const Item &it = per_job[j][next[j]];
-            // wave priority (s_setprio): the longest paths of the batch win the issue arbitration on their SIMDs
-            items.push_back(PgmItem{it.job, it.band, it.rem > 0.6 * rmax ? 3u : (it.rem > 0.35 * rmax ? 2u : (it.rem > 0.2 * rmax ? 1u : 0u)), it.count});
-            free_at.pop();
-            free_at.push(now + it.dur);
-            // the longest paths of the batch are not held back: their next band gets a worker at once (it spins until the
-            // predecessor is far enough, but then follows it without any queueing delay)
-            if (++next[j] < per_job[j].size()) pending.push({per_job[j][next[j]].rem > eager * rmax ? now : now + it.gap, j});
+            return end;
+        };
+        double band_end = 0.0;
+        if (total_b != 0) {
+            const uint32_t most = total != 0 ? capacity - 1u : capacity;
+            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.9 * t_goal))));
+            if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
+            else if (total != 0)
+                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.9 * t_goal) band_cus += std::max(1u, band_cus / 16u);
+            else band_cus = most;
+            band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
+            band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
+            capacity = std::max(1u, capacity - band_cus);
         }
+        b->nband_workers = band_cus;
+        // The jobs whose chains of sweeps are the longest of the batch (within 15 % of the longest: the root of a guide tree, as a
+        // rule) get a launch of the fill kernel of their own, on one CU per band: their tracebacks are the last thing a batch
+        // waits for, and this way the other jobs' tracebacks are out of the way before they start (each launch is followed by
+        // its own instance of pgm_tb_kernel).  Only if other jobs stay behind for the main launch.
+        size_t total_c = 0;
+        uint32_t crit_cus = 0;
+        if (use_bands && total != 0) {
+            uint32_t ncj = 0, nrestj = 0;
+            for (uint32_t i = 0; i < njobs; ++i) if (!per_job[i].empty()) { if (chain_of[i] >= 0.85 * rsweep) ++ncj; else ++nrestj; }
+            if (ncj != 0 && nrestj != 0) {
+                for (uint32_t i = 0; i < njobs; ++i)
+                    if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) { total_c += per_job[i].size(); per_job_c[i].swap(per_job[i]); }
+                crit_cus = (uint32_t)std::min<size_t>(total_c, capacity / 2u);
+                total -= total_c;
+                capacity -= crit_cus;
+            }
+        }
+        b->ncrit_workers = crit_cus;
+        std::vector<PgmItem> items_rest;
+        const double crit_end = total_c ? simulate(per_job_c, total_c, crit_cus, items) : 0.0;
+        b->ncrit = (uint32_t)items.size();
+        const double fill_end = simulate(per_job, total, capacity, items_rest);
+        items.insert(items.end(), items_rest.begin(), items_rest.end());
+        (void)crit_end;
+        if (cprof) fprintf(stderr, "    work lists: longest chain of sweeps %.0f us, goal %.0f us; lean %zu jobs %.0f us-worker on %u CUs; bands %zu, %.0f us-worker on %u CUs (simulated end %.0f us); items %zu, %.0f us-worker on %u CUs (simulated end %.0f us), of the longest chains %zu on %u CUs (%.0f us)\n",
+                           rsweep, t_goal, lean_list.size(), lean_cost, lean_cus, total_b, band_cost, band_cus, band_end, total, other_cost, capacity, fill_end, total_c, crit_cus, crit_end);
+        (void)fill_end;
     }
+    b->nbands = (uint32_t)bands.size();
+    if (bands.empty()) bands.push_back(PgmItem{0u, 0u, 0u, 0u});
     const double tc4 = now_ms();
     b->nitems = (uint32_t)items.size();
-    b->nworkers = std::max(1u, std::min(capacity, b->nitems));
+    b->nworkers = std::max(1u, std::min(capacity, b->nitems - b->ncrit));
     if (lean_list.empty()) lean_list.push_back(0u);
     if (tools_env("PGM_FILL_TRACE") && njobs &&   // (tools build) 6 words per item + 16 per item for the helper wavefronts, then 6 words per lean job
         hipMalloc((void **)&b->d_trace, 176 * items.size() + 48 * (size_t)njobs) != hipSuccess) {
@@ -982,13 +1086,23 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, "work list longer than the number of bands");
     }
-    std::vector<int2> tblist;
+    std::vector<int2> tblist;   // the jobs of the fill kernel's main launch (largest first), of its launch for the longest chains, of the band kernel: (job, its last item of the work list)
     {
-        std::vector<int> last_item(njobs, 0);
-        for (size_t k = 0; k < items.size(); ++k) if (items[k].band + items[k].count == b->jobs[items[k].job].nb) last_item[items[k].job] = (int)k;
-        for (uint32_t q = 0; q < njobs; ++q) { const uint32_t i = b->order[q]; if (!b->jobs[i].lean) tblist.push_back(make_int2((int)i, last_item[i])); }
-        b->ntb = (uint32_t)tblist.size();
-        b->ntb_workers = std::max(1u, std::min((uint32_t)std::max(1, ctx->prop.multiProcessorCount) - b->nlean_workers, std::max(b->ntb * 8u, 64u)));
+        std::vector<int> last_item(njobs, 0), group(njobs, 0);
+        for (size_t k = 0; k < items.size(); ++k) {
+            if (items[k].band + items[k].count == b->jobs[items[k].job].nb) last_item[items[k].job] = (int)k;
+            if (k < b->ncrit) group[items[k].job] = 1;
+        }
+        if (b->nbands) for (const PgmItem &it : bands) group[it.job] = 2;
+        uint32_t cnt[3] = {0, 0, 0};
+        for (int pass = 0; pass < 3; ++pass)
+            for (uint32_t q = 0; q < njobs; ++q) { const uint32_t i = b->order[q]; if (!b->jobs[i].lean && group[i] == pass) { tblist.push_back(make_int2((int)i, last_item[i])); ++cnt[pass]; } }
+        b->ntb = cnt[0]; b->ntb_c = cnt[1]; b->ntb_b = cnt[2];
+        // workers: the CUs of the kernel each instance follows (they are free by then; nothing of either grid is left waiting
+        // for a CU while other kernels of the batch still run)
+        const uint32_t all_cus = (uint32_t)std::max(1, ctx->prop.multiProcessorCount) - b->nlean_workers;
+        b->ntb_workers = std::max(1u, (b->ntb_b || b->ntb_c) ? b->nworkers : all_cus);
+        b->ntb_b_workers = std::max(1u, (b->ntb || b->ntb_c) ? b->nband_workers : all_cus);
         if (tblist.empty()) tblist.push_back(make_int2(0, 0));
     }
     if ((e = (hipError_t)upload_err.load()) != hipSuccess ||
@@ -997,6 +1111,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         (e = hipMemcpyAsync(b->d_order, b->order.data(), 4 * (size_t)njobs, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_lean, lean_list.data(), 4 * lean_list.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(b->d_bands, bands.data(), sizeof(PgmItem) * bands.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));
@@ -1004,6 +1119,8 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     for (int k = 0; k < 5; ++k) (void)hipEventCreate(&b->ev[k]);
     (void)hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&b->ev_join_b, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&b->ev_join_c, hipEventDisableTiming);
     if (cprof)
         fprintf(stderr, "    create: sizes %.2f ms, pinned input block %.2f, flatten %.2f, wait for the allocations %.2f (device %.2f, pinned results %.2f), work list %.2f, upload of %.1f MB %.2f\n",
                 tc0 - tcs, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc_alloc, tc_hostalloc, tc4 - tc3, b->in_bytes / 1e6, now_ms() - tc4);
@@ -1039,6 +1156,14 @@ int pgm_align_batch_time(pgm_ctx *ctx, pgm_align_batch *b, int reps, float *ms_p
     if (ms_emission) *ms_emission = (float)(acc[1] / reps);
     if (ms_fill) *ms_fill = (float)(acc[2] / reps);
     if (ms_traceback) *ms_traceback = (float)(acc[3] / reps);
+    return PGM_OK;
+}
+
+int pgm_align_batch_job_times(pgm_ctx *ctx, pgm_align_batch *b, uint64_t *ticks) {
+    if (!ctx || !b || !ticks) return fail(PGM_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (b->njobs) HIPCHK(hipMemcpy(ticks, b->d_times, 16 * (size_t)b->njobs, hipMemcpyDeviceToHost));
     return PGM_OK;
 }
 
@@ -1149,10 +1274,14 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (!b) return;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }   // nothing of the batch is in flight when its buffers go back to the cache
     if (ctx && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx && ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx && ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
     for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+    if (b->ev_join_b) (void)hipEventDestroy(b->ev_join_b);
+    if (b->ev_join_c) (void)hipEventDestroy(b->ev_join_c);
     cache_give(ctx, pgm_ctx::C_IN, b->d_in, b->cap[pgm_ctx::C_IN]);
     cache_give(ctx, pgm_ctx::C_WORK, b->d_work, b->cap[pgm_ctx::C_WORK]);
     cache_give(ctx, pgm_ctx::C_CELLS, b->d_cells, b->cap[pgm_ctx::C_CELLS]);

@@ -155,6 +155,9 @@ struct PgmJob {
     int *lready;
     uint32_t lrows, lcols; // grid rows, grid columns of the whole matrix
 
+    // timeline of the last launch (100 MHz ticks of s_memrealtime): [0] the job's last band complete, [1] its traceback published
+    unsigned long long *times;
+
     // DP storage
     float4 *cells;         // [nb][tsteps][R][64]
     int *prog;             // [nb] steps of band b that are complete and visible device-wide (zeroed before every launch)
@@ -172,10 +175,12 @@ struct PgmJob {
 
 
 // words of the batch's sync block the traceback kernel polls (a cache line of their own; [0] abort flag, [1] / [2] the tickets of the band and lean lists)
+#define PGM_SY_BAND_TICKET 3  // ticket counter of pgm_band_kernel's list (with the other tickets in the first cache line)
+#define PGM_SY_CRIT_TICKET 4  // ticket counter of the fill kernel's second launch (the jobs with the longest chains of sweeps)
 #define PGM_SY_LQ_N 32      // tracebacks that have started (pre-link announcements, ids in lq_ids)
 #define PGM_SY_TB_DONE 33   // tracebacks finished
 #define PGM_SY_TBQ_N 34     // ticket counter of the traceback kernel's job list
-#define PGM_LK_W 6u        // grid tiles per grid row in the corridor around the diagonal (paths of the headline batch stay within 40 columns of it)
+#define PGM_LK_W 4u        // grid tiles per grid row in the corridor around the diagonal (paths of the headline batch stay within 40 columns of it)
 #define PGM_LK_T 32u       // tile edge
 #define PGM_LK_MIN_ROWS 1216u   // jobs with fewer rows are not pre-linked (19 bands: the MODE 2 threshold)
 #define PGM_LK_H 16u       // halo above / left of a tile staged with it: predecessors up to this far outside the tile still get a link

@@ -18,6 +18,8 @@ subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.joi
 jobs = J.load_jobs(dump)
 if os.environ.get("PROBE_LEAF"):   # the chain-only jobs (leaf level) alone
     jobs = sorted(jobs, key=lambda j: j.cells)[:int(os.environ["PROBE_LEAF"])]
+if os.environ.get("PROBE_TOP"):    # the largest jobs alone (1: the root)
+    jobs = sorted(jobs, key=lambda j: -j.cells)[:int(os.environ["PROBE_TOP"])]
 os.environ["PGM_FILL_TRACE"] = trace
 for kv in os.environ.get("PROBE_ENV", "").split(","):   # experiment knobs that must not reach the product run above
     if "=" in kv:
@@ -67,7 +69,8 @@ tbi = np.where(tend > 0)[0]
 rel = (raw[tbi, 4] & np.uint64(0xffffffff)).astype(np.float64) / 100.0
 stg = (raw[tbi, 4] >> np.uint64(32)).astype(np.float64) / 100.0   # of which: loads -> LDS (the rest is the link pass)
 nrel = (raw[tbi, 5] >> np.uint64(32)).astype(np.float64)
-slow = (raw[tbi, 5] & np.uint64(0xffffffff)).astype(np.float64)
+slow = (raw[tbi, 5] & np.uint64(0xffff)).astype(np.float64)
+grid = ((raw[tbi, 5] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64)   # runs of the walker through pre-linked grid rows
 plen = np.array([sizes[items[i, 0]].sum() for i in tbi], dtype=np.float64)
 for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs[items[i, 0]].g1.n - 1 and jobs[items[i, 0]].g2.e_col.size == jobs[items[i, 0]].g2.n - 1 for i in tbi])),):
     for nm, mm in ((name, m), ("merged", ~m)):
@@ -75,7 +78,7 @@ for name, m in (("chain-only", np.array([jobs[items[i, 0]].g1.e_col.size == jobs
             print("traceback %-10s: %3d jobs, mean %.0f us, of which tile staging %.0f us in %.0f tiles (%.1f us/tile); slow steps %.0f of ~%.0f nodes; walking %.3f us/node" % (
                 nm, mm.sum(), tb[tbi][mm].mean(), rel[mm].mean(), nrel[mm].mean(), (rel[mm] / nrel[mm]).mean(), slow[mm].mean(), plen[mm].mean(), ((tb[tbi][mm] - rel[mm]) / plen[mm]).mean()))
 ri = [k for k, i in enumerate(tbi) if items[i, 0] == np.argmax(sizes[:, 0] * sizes[:, 1])][0]
-print("root traceback: %.0f us, tile staging %.0f us (loads -> LDS %.0f us, links %.0f us) in %.0f tiles (%.1f us/tile), slow steps %.0f" % (tb[tbi][ri], rel[ri], stg[ri], rel[ri] - stg[ri], nrel[ri], rel[ri] / nrel[ri], slow[ri]))
+print("root traceback: %.0f us, tile staging %.0f us (loads -> LDS %.0f us, links %.0f us) in %.0f tiles (%.1f us/tile), slow steps %.0f, runs through pre-linked rows %.0f" % (tb[tbi][ri], rel[ri], stg[ri], rel[ri] - stg[ri], nrel[ri], rel[ri] / max(nrel[ri], 1), slow[ri], grid[ri]))
 print("all merged: loads -> LDS %.1f us/tile, links %.1f us/tile; chain-only: %.1f / %.1f" % ((stg[~m] / nrel[~m]).mean(), ((rel[~m] - stg[~m]) / nrel[~m]).mean(), (stg[m] / nrel[m]).mean(), ((rel[m] - stg[m]) / nrel[m]).mean()))
 # step time per class of job: (band end - start - wait) / (steps of the item's last band + its start offset)
 cnt = np.frombuffer(buf, np.uint32, 4 * n, 4).reshape(n, 4)[:, 3]
