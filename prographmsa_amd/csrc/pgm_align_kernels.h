@@ -470,9 +470,9 @@ struct PgmTbLds {
     uint32_t len;
     int nbig;                                  // cells of the link band whose nodes have 5..8 predecessors (M link by a whole wavefront)
     uint16_t big[128];
-    uint16_t gtab[PGM_LK_W * PGM_LK_TAB] __attribute__((aligned(16)));   // the pre-linked tables of the grid row the walker is in (copy of PgmJob::ltab[grow])
-    uint32_t grow;                             // that row (0xFFFFFFFF: none)
-    uint32_t gnext;                            // 1: the row above it was complete when this one was loaded
+    uint16_t gtab[PGM_LK_NR][PGM_LK_W * PGM_LK_TAB] __attribute__((aligned(16)));   // pre-linked tables of up to PGM_LK_NR grid rows (copies of PgmJob::ltab[row]), ring slot = row % PGM_LK_NR
+    uint32_t grow, gcnt;                       // request: load the rows grow, grow - 1, ..., grow - gcnt + 1
+    uint32_t gnext[PGM_LK_NR];                 // [k] = 1: row grow - gcnt - k was complete when the request was served (looked at in the same round trip)
 };
 
 // Staging of one grid tile for pgm_prelink_tile: the tile's cells with a halo of PGM_LK_H rows above and columns to the left
@@ -753,24 +753,33 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
     // fast evaluation below, the root's traceback went from 0.93 to 1.27 ms.  The links stay; the fast evaluation serves the
     // cells without one.)
     const bool use_links = true;
-    // the pre-linked tables of grid row T.grow -> LDS, all threads (36 KB: nine 8-byte device-coherent loads each, one round trip);
-    // with them the completion count of the row above, which is where the walker goes next
-    auto load_row = [&]() {
-        const uint32_t gy = T.grow;
-        constexpr uint32_t NW = PGM_LK_W * PGM_LK_TAB * 2u / 8u, NT = 64u * PGM_WAVES;
+    // the pre-linked tables of the grid rows T.grow, T.grow - 1, ... (T.gcnt of them, all known to be complete) -> LDS, all
+    // threads: six 8-byte device-coherent loads per row and thread, all rows in one round trip; with them the completion counts
+    // of the PGM_LK_NR rows above, which is where the walker goes next
+    auto load_rows = [&]() {
+        const uint32_t gy = T.grow, cnt = T.gcnt;
+        constexpr uint32_t NW = PGM_LK_W * PGM_LK_TAB * 2u / 8u, NT = 64u * PGM_WAVES, PER = NW / NT;
         static_assert(NW % NT == 0u, "row table: whole rounds of the workgroup");
-        const PGM_GLOBAL unsigned long long *src = (const PGM_GLOBAL unsigned long long *)(uintptr_t)(J.ltab + (size_t)gy * (PGM_LK_W * PGM_LK_TAB));
-        unsigned long long v[NW / NT];
+        unsigned long long v[PGM_LK_NR][PER];
 #pragma unroll
-        for (uint32_t q = 0; q < NW / NT; ++q) v[q] = __hip_atomic_load(src + (uint32_t)tid + NT * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t r = 0; r < PGM_LK_NR; ++r) {
+            const PGM_GLOBAL unsigned long long *src = (const PGM_GLOBAL unsigned long long *)(uintptr_t)(J.ltab + (size_t)(gy - min(r, cnt - 1u)) * (PGM_LK_W * PGM_LK_TAB));
+#pragma unroll
+            for (uint32_t q = 0; q < PER; ++q) v[r][q] = r < cnt ? __hip_atomic_load(src + (uint32_t)tid + NT * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
         uint32_t nx = 0u;
-        if (tid == 64 && gy != 0u) nx = (uint32_t)__hip_atomic_load(J.lready + (gy - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= min(J.lcols, PGM_LK_W) ? 1u : 0u;
+        const uint32_t k = (uint32_t)tid - 64u;
+        if (k < PGM_LK_NR && gy >= cnt + k) nx = (uint32_t)__hip_atomic_load(J.lready + (gy - cnt - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= min(J.lcols, PGM_LK_W) ? 1u : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < NW / NT; ++q) ((unsigned long long *)T.gtab)[(uint32_t)tid + NT * q] = v[q];
-        if (tid == 64) T.gnext = nx;
+        for (uint32_t r = 0; r < PGM_LK_NR; ++r)
+            if (r < cnt) {
+#pragma unroll
+                for (uint32_t q = 0; q < PER; ++q) ((unsigned long long *)T.gtab[(gy - r) % PGM_LK_NR])[(uint32_t)tid + NT * q] = v[r][q];
+            }
+        if (k < PGM_LK_NR) T.gnext[k] = nx;
     };
     if (tid == 0) {
-        T.grow = 0xFFFFFFFFu; T.gnext = 0u;
+        T.grow = 0xFFFFFFFFu; T.gcnt = 0u;
         if (J.lrows != 0u) __hip_atomic_store(J.lready + J.lrows + 1, (int)(J.lrows - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         T.ty0 = n1 - 2 >= TT - 1 ? n1 - 2 - (TT - 1) : 0u;
         T.tx0 = n2 - 2 >= TT - 1 ? n2 - 2 - (TT - 1) : 0u;
@@ -796,7 +805,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         for (;;) {
             __syncthreads();            // request posted
             if (T.req == 2) break;
-            if (T.req == 3) { load_row(); __syncthreads(); continue; }
+            if (T.req == 3) { load_rows(); __syncthreads(); continue; }
             stage();
             __syncthreads();            // cells, scores, predecessor lists staged
             if (use_links) {
@@ -909,8 +918,8 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         unsigned long long st_reload = 0, st_nreload = 0, st_slow = 0, st_stage = 0, st_grid = 0;
         bool score_stale = false;
         uint32_t nl_y = 0xFFFFFFFFu, nl_x = 0xFFFFFFFFu;   // last cell at which the pre-linked tables had nothing to follow
-        uint32_t grow = 0xFFFFFFFFu;                       // grid row whose tables are in LDS
-        bool gnext = false;
+        uint32_t glo = 1u, ghi = 0u;                       // grid rows whose tables are in LDS (none: lo > hi)
+        uint32_t known = 0u;                               // rows below glo known to be complete
         while ((x != 0 || y != 0) && status == PGM_OK) {
             if (++guard > n1 + n2 + 4) { status = PGM_ERR_BACKTRACK; break; }
             // the walker state is the same in all lanes: keep it in scalar registers so that the branches below are scalar
@@ -933,25 +942,32 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     if (gy >= J.lrows) break;
                     const uint32_t first = pgm_lk_first(n1, n2, J.lcols, gy);
                     if ((x >> 5) - first >= gw) break;                      // outside the corridor
-                    if (grow != gy) {
-                        // the row's tables: complete?  (known from the look-ahead of the previous row's load, else one flag round trip)
-                        bool ready = gy + 1u == grow && gnext;
-                        if (!ready) ready = (uint32_t)__hip_atomic_load(J.lready + gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gw;
-                        if (!ready) break;
+                    if (!(gy >= glo && gy <= ghi)) {                        // row gy is not among the rows in LDS
+                        // how many rows to fetch: gy, and as many below it as are KNOWN to be complete (from the look-ahead of the
+                        // previous request, when gy continues the rows in LDS); gy itself costs a flag round trip otherwise
+                        const bool cont = gy + 1u == glo && known != 0u;
+                        if (!cont) {
+                            if ((uint32_t)__hip_atomic_load(J.lready + gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gw) break;
+                            known = 1u;
+                        }
+                        const uint32_t cnt = min(min(known, (uint32_t)PGM_LK_NR), gy + 1u);
                         if (lane == 0) {
-                            T.grow = gy; T.req = 3;
-                            __hip_atomic_store(J.lready + J.lrows + 1, (int)gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // rows above gy are still wanted
+                            T.grow = gy; T.gcnt = cnt; T.req = 3;
+                            __hip_atomic_store(J.lready + J.lrows + 1, (int)(gy >= cnt ? gy - cnt : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the rows from there up are still wanted
                         }
                         __syncthreads();        // request posted
-                        load_row();
+                        load_rows();
                         __syncthreads();
-                        grow = gy; gnext = T.gnext != 0u;
+                        ghi = gy; glo = gy + 1u - cnt;
+                        known = 0u;
+                        while (known < (uint32_t)PGM_LK_NR && T.gnext[known] != 0u) ++known;
                     }
                     bool left_row = false;
+                    const uint16_t *tab = T.gtab[gy % PGM_LK_NR];
                     for (;;) {
                         const uint32_t j = (x >> 5) - first;
                         if (j >= gw) break;
-                        const uint32_t code = T.gtab[j * PGM_LK_TAB + st * (TT * TT) + (y & 31u) * TT + (x & 31u)];
+                        const uint32_t code = tab[j * PGM_LK_TAB + st * (TT * TT) + (y & 31u) * TT + (x & 31u)];
                         if (!(code & 0x8000u)) break;
                         y -= (code >> 6) & 63u; x -= code & 63u; st = (code >> 12) & 3u;
                         moved = true;

@@ -182,6 +182,7 @@ struct PgmJob {
 #define PGM_SY_TBQ_N 34     // ticket counter of the traceback kernel's job list
 #define PGM_LK_W 4u        // grid tiles per grid row in the corridor around the diagonal (paths of the headline batch stay within 40 columns of it)
 #define PGM_LK_T 32u       // tile edge
+#define PGM_LK_NR 4u       // grid rows of tables a walker keeps in LDS (fetched together when known to be complete)
 #define PGM_LK_MIN_ROWS 1216u   // jobs with fewer rows are not pre-linked (19 bands: the MODE 2 threshold)
 #define PGM_LK_H 16u       // halo above / left of a tile staged with it: predecessors up to this far outside the tile still get a link
 #define PGM_LK_TAB (3u * PGM_LK_T * PGM_LK_T)   // links per tile

@@ -14,6 +14,9 @@ subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/
 jobs = J.load_jobs(dump)
 if os.environ.get("PROBE_TOP"):    # the largest jobs alone (7: the MODE 2 jobs; 127: everything but the leaf level)
     jobs = sorted(jobs, key=lambda j: -j.cells)[:int(os.environ["PROBE_TOP"])]
+if os.environ.get("PROBE_SET"):    # the root with one kind of company: "lean" (the leaf level), "mid" (the jobs below 1216 rows), "big" (the other six)
+    srt = sorted(jobs, key=lambda j: -j.cells)
+    jobs = srt[:1] + {"lean": srt[127:], "mid": srt[7:127], "big": srt[1:7], "midlean": srt[7:]}[os.environ["PROBE_SET"]]
 ctx = pg.Context(0)
 b = J.Batch(ctx, jobs)
 for rep in range(2):
