@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$1
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="python3 bench.py --warmup 1 --no-cpu-baseline --no-extra"
+B="python3 bench.py --warmup 1 --only-headline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $B --steps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $B --steps 2 > /dev/null 2> "$OUT/fetch.err"
