@@ -976,8 +976,9 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         }
         // The CUs are split between the kernels (one worker per CU in each).  All three are waited for before the tracebacks start,
         // so the time to beat is the longer of the longest chain of sweeps (rsweep) and the whole queue over all CUs: the lean
-        // queue gets the fewest CUs with which it is done within 0.75 of that, the band queue (eight bands at a time per CU) the
-        // fewest with which its simulated schedule ends within 0.9 of it, the fill kernel — one band of a MODE 2 job per CU, the
+        // queue gets the fewest CUs with which it is done within 0.6 of that, the band queue (eight bands at a time per CU) the
+        // fewest with which its simulated schedule ends within 0.75 of it (both measured on the headline batch, tools/ab_lib.sh:
+        // the sooner their traffic is out of the way the faster the longest chain runs, until the main launch starves), the fill kernel — one band of a MODE 2 job per CU, the
         // chains that bound the batch — the rest.
         double band_cost = 0.0;
         for (uint32_t i = 0; i < njobs; ++i) { for (const Item &it : per_job[i]) other_cost += it.dur; for (const Item &it : per_job_b[i]) band_cost += it.dur / PGM_WAVES; }
@@ -988,7 +989,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
             if (total + total_b != 0) {
                 const uint32_t lo = std::min(4u, capacity - 1u);
                 for (lean_cus = lo; lean_cus + 4u < capacity; ++lean_cus)
-                    if (lean_cost / lean_cus <= 0.75 * std::max(t_goal, (other_cost + band_cost) / (double)(capacity - lean_cus))) break;
+                    if (lean_cost / lean_cus <= 0.6 * std::max(t_goal, (other_cost + band_cost) / (double)(capacity - lean_cus))) break;
             }
             if (const char *v = tools_env("PGM_LEAN_CUS")) lean_cus = std::max(1u, std::min(capacity - (total + total_b != 0 ? 1u : 0u), (uint32_t)atoi(v)));
             lean_cus = std::min<uint32_t>(lean_cus, (uint32_t)lean_list.size());
@@ -1032,10 +1033,10 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         double band_end = 0.0;
         if (total_b != 0) {
             const uint32_t most = total != 0 ? capacity - 1u : capacity;
-            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.9 * t_goal))));
+            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.75 * t_goal))));
             if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
             else if (total != 0)
-                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.9 * t_goal) band_cus += std::max(1u, band_cus / 16u);
+                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.75 * t_goal) band_cus += std::max(1u, band_cus / 16u);
             else band_cus = most;
             band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
             band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
