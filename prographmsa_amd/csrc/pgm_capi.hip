@@ -210,7 +210,11 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+    {   // (the launch of the longest chains on the highest stream priority the device offers)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        HIPCHK(hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, hi));
+    }
     hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
