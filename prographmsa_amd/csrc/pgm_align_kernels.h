@@ -471,6 +471,7 @@ struct PgmTbLds {
     int nbig;                                  // cells of the link band whose nodes have 5..8 predecessors (M link by a whole wavefront)
     uint16_t big[128];
     uint16_t gtab[PGM_LK_NR][PGM_LK_W * PGM_LK_TAB] __attribute__((aligned(16)));   // pre-linked tables of up to PGM_LK_NR grid rows (copies of PgmJob::ltab[row]), ring slot = row % PGM_LK_NR
+    uint2 mbuf[64];                            // mapping entries of a link chase, written out 64 at a time
     uint32_t grow, gcnt;                       // request: load the rows grow, grow - 1, ..., grow - gcnt + 1
     uint32_t gnext[PGM_LK_NR];                 // [k] = 1: row grow - gcnt - k was complete when the request was served (looked at in the same round trip)
 };
@@ -911,6 +912,20 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
         // one ballot finds; only if no lane is exact the minimum is searched lane by lane.
         auto rl_u = [](uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
         auto rl_f = [](float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+        // mapping entries of a link chase: one LDS word pair per path node (lane 0), written to memory by all lanes 64 at a time
+        // (two global stores per node cost the lone walker more than the link read itself)
+        uint32_t nbuf = 0;
+        auto buf_flush = [&]() {
+            if (nbuf != 0u) {
+                if ((uint32_t)lane < nbuf && mo.len + (uint32_t)lane < mo.cap) { const uint2 v = T.mbuf[lane]; mo.m1[mo.len + (uint32_t)lane] = v.x; mo.m2[mo.len + (uint32_t)lane] = v.y; }
+                mo.len += nbuf;
+                nbuf = 0u;
+            }
+        };
+        auto buf_push = [&](uint32_t a, uint32_t b2) {
+            if (lane == 0) T.mbuf[nbuf] = make_uint2(a, b2);
+            if (++nbuf == 64u) buf_flush();
+        };
         // a new tile is staged when the walker is closer than `margin` to the tile's low edge: predecessors of chain-only
         // graphs are 1 node back; in merged graphs most skip edges span a few nodes (farther ones are read from memory)
         const uint32_t margin = J.has_extras ? 4u : 1u;
@@ -972,13 +987,13 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                         y -= (code >> 6) & 63u; x -= code & 63u; st = (code >> 12) & 3u;
                         moved = true;
                         if ((y | x) == 0u) break;
-                        if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = st == 1u ? 0xFFFFFFFFu : y; mo.m2[mo.len] = st == 2u ? 0xFFFFFFFFu : x; }
-                        ++mo.len;
+                        buf_push(st == 1u ? 0xFFFFFFFFu : y, st == 2u ? 0xFFFFFFFFu : x);
                         if ((y >> 5) != gy) { left_row = true; break; }
                     }
                     y = __builtin_amdgcn_readfirstlane(y); x = __builtin_amdgcn_readfirstlane(x); st = __builtin_amdgcn_readfirstlane(st);
                     if (!left_row) break;
                 }
+                buf_flush();
                 if (moved) {
                     current_state = st == 0u ? State_m : (st == 1u ? State_x : State_y);
                     score_stale = true;
@@ -1018,9 +1033,9 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                     moved = true;
                     const uint32_t ny = ty0 + ((pos >> 5) & 31u), nx = tx0 + (pos & 31u), st = pos >> 10;
                     if ((ny | nx) == 0u) break;
-                    if (lane == 0 && mo.len < mo.cap) { mo.m1[mo.len] = st == 1u ? 0xFFFFFFFFu : ny; mo.m2[mo.len] = st == 2u ? 0xFFFFFFFFu : nx; }
-                    ++mo.len;
+                    buf_push(st == 1u ? 0xFFFFFFFFu : ny, st == 2u ? 0xFFFFFFFFu : nx);
                 }
+                buf_flush();
                 if (moved) {
                     y = ty0 + ((pos >> 5) & 31u); x = tx0 + (pos & 31u);
                     const uint32_t st = pos >> 10;
