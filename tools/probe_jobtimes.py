@@ -8,9 +8,13 @@ import gen
 import prographmsa_amd as pg
 from prographmsa_amd import jobs as J
 tmp = tempfile.mkdtemp()
-fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(gen.gen(256, 1000, 3)))
+cfg = os.environ.get("PROBE_CFG", "c3")   # c3: headline batch; c4 / c5: the heavy-tailed configs
+fam, flags = {"c3": (lambda: gen.gen(256, 1000, 3), ["--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree")]),
+              "c4": (lambda: gen.gen_codon(128, 1000, 4), ["--codon", "--fasta", "-t", os.path.join(ROOT, "tests/golden/c4.tree")]),
+              "c5": (lambda: gen.gen(1024, 600, 6), ["--fasta", "-t", os.path.join(ROOT, "tests/golden/c5.tree")])}[cfg]
+fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam()))
 dump = os.path.join(tmp, "jobs.bin")
-subprocess.run([pg.PGMSA_PATH, "--fasta", "-m", "-t", os.path.join(ROOT, "tests/golden/c3.tree"), "--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True)
+subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True, env=dict(os.environ, PGM_HOST_PROFILE="1" if os.environ.get("PROBE_LISTS") else "0"))
 jobs = J.load_jobs(dump)
 if os.environ.get("PROBE_TOP"):    # the largest jobs alone (7: the MODE 2 jobs; 127: everything but the leaf level)
     jobs = sorted(jobs, key=lambda j: -j.cells)[:int(os.environ["PROBE_TOP"])]
@@ -32,6 +36,7 @@ for rep in range(2):
     n1 = np.array([j.g1.n for j in jobs])
     print("launch %d: fill stage %.0f us" % (rep, fill_us))
     for name, m in (("chain-only (lean kernel)", chain), ("< 1216 rows", ~chain & (n1 < 1217)), (">= 1216 rows", ~chain & (n1 >= 1217))):
+        m = np.asarray(m)
         if m.any():
             print("  %-26s %3d jobs: last sweep ends %5.0f us (median %5.0f), last traceback published %5.0f us (median %5.0f)" % (name, m.sum(), sw[m].max(), np.median(sw[m]), dn[m].max(), np.median(dn[m])))
     for i in np.argsort(-dn)[:6]:
