@@ -163,6 +163,34 @@ def test_handoff_timeout_aborts_the_batch(ctx):
     b.close()
 
 
+def test_job_timeline(ctx):
+    """pgm_align_batch_job_times: every job of a mixed batch (chain-only jobs in the lean kernel, bands one per wavefront, a MODE 2 job
+    with a pre-linked corridor) has a sweep end and a later publication stamp, all within the launch; pgm_align_batch_stage_times
+    counts exactly the fetched launches."""
+    import ctypes as C
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    js = [J.random_job(900 + i, n1, n2, **kw) for i, (n1, n2, kw) in enumerate([
+        (300, 280, dict(skip_frac=0.0, drop_chain_frac=0.0)), (500, 510, dict(skip_frac=0.2)), (260, 300, dict(skip_frac=0.3, repeat_frac=0.05)),
+        (1400, 1350, dict(skip_frac=0.25, skip_span=27, skip_max=2)), (90, 80, dict(skip_frac=0.0, drop_chain_frac=0.0))])]
+    b = J.Batch(ctx, js)
+    for _ in range(3):
+        b.run(); res = b.fetch()
+    assert all(r["status"] == 0 for r in res)
+    t = np.zeros(2 * len(js), np.uint64)
+    pg.check(pg.lib.pgm_align_batch_job_times(ctx.handle, b.handle, t.ctypes.data_as(C.POINTER(C.c_uint64))))
+    t = t.reshape(-1, 2).astype(np.int64)
+    assert (t > 0).all() and (t[:, 1] >= t[:, 0]).all()
+    assert (t.max() - t.min()) < 100 * 100000          # within 100 ms (10 ns ticks)
+    ms = b.stage_times(reset=True)
+    assert ms[3] == 3 and ms[2] > 0 and b.stage_times()[3] == 0
+    import oracle_lib
+    for j, r in zip(js, res):
+        ref = oracle_lib.align_graphs(j)
+        assert np.array_equal(r["map1"], ref["map1"]) and np.array_equal(r["map2"], ref["map2"])
+    b.close()
+
+
 def test_empty_batch(ctx):
     from prographmsa_amd import jobs as J
     assert J.align_graphs_batch(ctx, []) == []
