@@ -113,6 +113,22 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                               const pgm_graph *const *g2, const pgm_model *const *model,
                               const pgm_scores *scores, uint32_t flags, pgm_align_batch **out);
+/* Graphs whose node profiles already are in HBM (left there by pgm_merge_profiles_batch_ex with PGM_MERGE_RESIDENT): for job i,
+ * res1[i].dev_sites != NULL replaces g1[i]->sites (which may then be NULL) by that device matrix, gathered through
+ * res1[i].node_map — node v of the graph handed over (a CleanedGraph, src/CleanedGraph.h:39-146) has the profile in column
+ * node_map[v] of the matrix (the merged graph it was cleaned from); node_map == NULL: column v.  res1 / res2 may be NULL. */
+typedef struct pgm_site_ref {
+    const double *dev_sites;
+    const uint32_t *node_map; /* host array, n entries */
+} pgm_site_ref;
+int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
+                               const pgm_graph *const *g2, const pgm_model *const *model,
+                               const pgm_scores *scores, uint32_t flags, const pgm_site_ref *res1,
+                               const pgm_site_ref *res2, pgm_align_batch **out);
+int pgm_align_graphs_batch_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
+                               const pgm_graph *const *g2, const pgm_model *const *model,
+                               const pgm_scores *scores, const pgm_site_ref *res1,
+                               const pgm_site_ref *res2, pgm_align_out *out);
 int pgm_align_batch_run(pgm_ctx *ctx, pgm_align_batch *b);
 int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out);
 void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b);
@@ -242,6 +258,13 @@ typedef struct pgm_merge_job {
     double *profiles;              /* out: dim x nnodes column-major */
 } pgm_merge_job;
 int pgm_merge_profiles_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs);
+/* The same with the results LEFT IN HBM (flags & PGM_MERGE_RESIDENT): dev_profiles[i] receives the device address of job i's
+ * dim x nnodes matrix, jobs[i].profiles may be NULL and nothing is copied back; sites1 / sites2 of a job may themselves be such
+ * addresses (the children's profiles never left the device).  The matrices of one call stay valid until the third-next resident
+ * call on the context (a guide-tree level's graphs are read by the next level's alignments — pgm_site_ref — and merges only). */
+#define PGM_MERGE_RESIDENT 1u
+int pgm_merge_profiles_batch_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs, uint32_t flags,
+                                const double **dev_profiles);
 float pgm_merge_last_kernel_ms(pgm_ctx *ctx);
 
 #ifdef __cplusplus

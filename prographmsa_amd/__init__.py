@@ -19,6 +19,7 @@ PGM_OK, PGM_ERR_INVALID, PGM_ERR_DEVICE, PGM_ERR_BACKTRACK, PGM_ERR_NOMEM = 0, 1
 PGM_GAP = 0xFFFFFFFF
 PGM_BATCH_KEEP_MATRICES = 1
 PGM_NW_REDUCED = 1
+PGM_MERGE_RESIDENT = 1
 
 
 class pgm_graph(C.Structure):
@@ -48,6 +49,10 @@ class pgm_merge_job(C.Structure):
                 ("k1", C.POINTER(C.c_uint32)), ("k2", C.POINTER(C.c_uint32)), ("g2_with_P1", C.POINTER(C.c_uint8)), ("profiles", C.POINTER(C.c_double))]
 
 
+class pgm_site_ref(C.Structure):
+    _fields_ = [("dev_sites", C.POINTER(C.c_double)), ("node_map", C.POINTER(C.c_uint32))]
+
+
 class pgm_align_out(C.Structure):
     _fields_ = [("score", C.c_float), ("n_tr_indels", C.c_uint32), ("len", C.c_uint32), ("status", C.c_int32),
                 ("map1", C.POINTER(C.c_uint32)), ("map2", C.POINTER(C.c_uint32))]
@@ -56,11 +61,11 @@ class pgm_align_out(C.Structure):
 # every symbol include/pgm_hip.h declares
 EXPORTS = [
     "pgm_device_count", "pgm_ctx_create", "pgm_ctx_destroy", "pgm_last_error", "pgm_ctx_device_info",
-    "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_run", "pgm_align_batch_fetch",
+    "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_create_res", "pgm_align_graphs_batch_res", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_align_batch_stage_times", "pgm_align_batch_job_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
-    "pgm_merge_profiles_batch", "pgm_merge_last_kernel_ms",
+    "pgm_merge_profiles_batch", "pgm_merge_profiles_batch_ex", "pgm_merge_last_kernel_ms",
 ]
 
 
@@ -80,6 +85,8 @@ def _load():
         "pgm_align_graphs_batch": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), C.POINTER(pgm_align_out)]),
         "pgm_align_batch_create": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), C.POINTER(vp)]),
         "pgm_align_batch_create_ex": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), u32, C.POINTER(vp)]),
+        "pgm_align_batch_create_res": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), u32, C.POINTER(pgm_site_ref), C.POINTER(pgm_site_ref), C.POINTER(vp)]),
+        "pgm_align_graphs_batch_res": (C.c_int, [vp, u32, PG, PG, PM, C.POINTER(pgm_scores), C.POINTER(pgm_site_ref), C.POINTER(pgm_site_ref), C.POINTER(pgm_align_out)]),
         "pgm_align_batch_run": (C.c_int, [vp, vp]),
         "pgm_align_batch_fetch": (C.c_int, [vp, vp, C.POINTER(pgm_align_out)]),
         "pgm_align_batch_destroy": (None, [vp, vp]),
@@ -106,6 +113,7 @@ def _load():
         "pgm_kmer_cosine": (C.c_int, [vp, u32, u32, C.POINTER(i32), C.POINTER(C.c_double)]),
         "pgm_dist_last_kernel_ms": (C.c_float, [vp]),
         "pgm_merge_profiles_batch": (C.c_int, [vp, u32, C.POINTER(pgm_merge_job)]),
+        "pgm_merge_profiles_batch_ex": (C.c_int, [vp, u32, C.POINTER(pgm_merge_job), u32, C.POINTER(C.POINTER(C.c_double))]),
         "pgm_merge_last_kernel_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():

@@ -80,10 +80,12 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
     }
     if (!first) for (uint32_t i = threadIdx.x; i < D * D; i += NODES) Mf[i] = (float)J.M[i];
     for (uint32_t i = threadIdx.x; i < D; i += NODES) pif[i] = (float)J.pi[i];
-    const double *src = (first ? J.sites1 : J.sites2) + (size_t)D * v0;
+    const double *sites = first ? J.sites1 : J.sites2;
+    const uint32_t *smap = first ? J.smap1 : J.smap2;   // (profiles left in HBM by the merge of the level below: gathered through the cleaned graph's node map)
     float *dst = (first ? J.g1f : J.t2) + (size_t)DP * v0;
     for (uint32_t i = threadIdx.x; i < nn * D; i += NODES) {
-        const float g = (float)src[i];
+        const uint32_t node = v0 + i / D;
+        const float g = (float)sites[(size_t)D * (smap ? smap[node] : node) + i % D];
         nl[(i / D) * ST + (i % D)] = g;
         if (first && DP == D) dst[i] = g;                     // g1f is the converted column itself
     }

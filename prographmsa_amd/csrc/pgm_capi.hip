@@ -48,6 +48,7 @@ struct pgm_ctx {
     int device = 0;
     PgmNwState *nw = nullptr;        // the all-pairs stage's two tiles in flight (pgm_nw_capi.inc)
     int nw_per_cu = 0;
+    uint32_t res_next = 0;           // resident merge results: next buffer of the ring (scratch slots 16..18)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
     hipStream_t stream3 = nullptr;   // ... and so does the band kernel (pgm_band_kernel)
@@ -266,6 +267,8 @@ int pgm_ctx_device_info(pgm_ctx *ctx, char *name, size_t name_len, int *cu_count
 namespace {
 struct SideOff {
     size_t sites, ni, xp, xc, xv, pp, pc, pv, pu, fp, fe, ov;
+    size_t smap = 0;              // resident profiles: the node -> column map of the side
+    bool has_smap = false;
     uint32_t nodes_with_extras;   // nodes with a predecessor other than the chain neighbour
     uint32_t has_long;            // some edge outside the near slots is longer than PGM_DCAP
     uint32_t maxd_cap;            // largest distance <= PGM_DCAP of an edge outside the chain slot (>= 1)
@@ -281,9 +284,10 @@ struct SideOff {
     std::vector<float> cv;
 };
 
-static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o) {
+static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, SideOff &o, const pgm_site_ref *res = nullptr) {
     const uint32_t n = g->n;
-    if (n < 2 || !g->sites || !g->e_rowptr) return PGM_ERR_INVALID;
+    const bool resident = res && res->dev_sites;
+    if (n < 2 || (!g->sites && !resident) || !g->e_rowptr) return PGM_ERR_INVALID;
     std::vector<float> xv, pv;
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
@@ -343,7 +347,11 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     // at least one element each so that pointers are valid
     if (xc.empty()) { xc.push_back(0); xv.push_back(0); }
     if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
-    o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);
+    o.smap = 0; o.has_smap = false;
+    if (resident) {   // the profiles are in HBM already (pgm_merge_profiles_batch_ex): only the node -> column map travels
+        o.sites = 0;
+        if (res->node_map) { o.smap = A.put(res->node_map, 4 * (size_t)n); o.has_smap = true; }
+    } else o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);
     o.ni = A.put(ni.data(), sizeof(PgmNode2) * ni.size());
     o.xp = A.put(xp.data(), 4 * xp.size());
     o.xc = A.put(xc.data(), 4 * xc.size());
@@ -649,6 +657,12 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 
 int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                               const pgm_model *const *model, const pgm_scores *scores, uint32_t flags, pgm_align_batch **out) {
+    return pgm_align_batch_create_res(ctx, njobs, g1, g2, model, scores, flags, nullptr, nullptr, out);
+}
+
+int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                               const pgm_model *const *model, const pgm_scores *scores, uint32_t flags,
+                               const pgm_site_ref *res1, const pgm_site_ref *res2, pgm_align_batch **out) {
     if (!ctx || !out || (njobs && (!g1 || !g2 || !model || !scores))) return fail(PGM_ERR_INVALID, "null argument");
     *out = nullptr;
     HIPCHK(hipSetDevice(ctx->device));
@@ -661,17 +675,19 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
     std::vector<Off> off(njobs);
     b->res_off.resize(njobs); b->map1_off.resize(njobs); b->map2_off.resize(njobs);
     // pass 1 (serial, O(jobs)): sizes, device layouts, and an upper bound of each job's flattened input
-    auto side_bound = [](const pgm_graph *g) -> size_t {
+    auto side_bound = [](const pgm_graph *g, const pgm_site_ref *res) -> size_t {
         const size_t n = g->n;
         size_t E = (size_t)std::max(0, g->e_rowptr ? g->e_rowptr[n] : 0);
         if (g->r_rowptr) E += (size_t)std::max(0, g->r_rowptr[n]);
-        return side_bound_bytes(n, g->dim, E);
+        const size_t full = side_bound_bytes(n, g->dim, E);
+        return (res && res->dev_sites) ? full - n * g->dim * 8 + n * 4 + 16 : full;   // (resident profiles: a map of n words instead)
     };
+    auto ref_of = [&](const pgm_site_ref *r, uint32_t i) -> const pgm_site_ref * { return (r && r[i].dev_sites) ? &r[i] : nullptr; };
     std::vector<size_t> in_base(njobs + 1, 0);
     for (uint32_t i = 0; i < njobs; ++i) {
         const pgm_graph *a = g1[i], *c = g2[i];
         if (!a || !c || !model[i] || a->dim != c->dim || a->dim == 0 || a->dim > 64 || a->n < 2 || c->n < 2 || !model[i]->M || !model[i]->pi ||
-            !a->sites || !a->e_rowptr || !c->sites || !c->e_rowptr) {
+            (!a->sites && !ref_of(res1, i)) || !a->e_rowptr || (!c->sites && !ref_of(res2, i)) || !c->e_rowptr) {
             delete b;
             return fail(PGM_ERR_INVALID, "invalid job " + std::to_string(i));
         }
@@ -697,7 +713,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         b->maxnb = std::max(b->maxnb, J.nb << J.rshift);   // (bands of the emission kernel: R virtual bands per band)
         b->cells += (uint64_t)(a->n - 2) * (c->n - 2);
         Off &o = off[i];
-        in_base[i + 1] = in_base[i] + side_bound(a) + side_bound(c) + model_bound_bytes(a->dim);
+        in_base[i + 1] = in_base[i] + side_bound(a, ref_of(res1, i)) + side_bound(c, ref_of(res2, i)) + model_bound_bytes(a->dim);
         J.keep_cells = (!J.lean || (flags & PGM_BATCH_KEEP_MATRICES)) ? 1u : 0u;
         layout_job(L, J.n1, J.n2, J.dim, J.rshift, J.lean != 0, J.keep_cells != 0, o);
         b->res_off[i] = o.res; b->map1_off[i] = o.map1; b->map2_off[i] = o.map2;
@@ -786,7 +802,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
                 A.base = b->h_in; A.off = in_base[i]; A.end = in_base[i + 1];
                 PgmJob &J = b->jobs[i];
                 Off &o = off[i];
-                if (flatten_side(g1[i], J.sc, A, o.s1) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2) != PGM_OK) { bad.store((int)i); return; }
+                if (flatten_side(g1[i], J.sc, A, o.s1, ref_of(res1, i)) != PGM_OK || flatten_side(g2[i], J.sc, A, o.s2, ref_of(res2, i)) != PGM_OK) { bad.store((int)i); return; }
                 J.has_extras = (o.s1.nodes_with_extras + o.s2.nodes_with_extras) > 0 ? 1u : 0u;
                 if (J.lean && J.has_extras) { bad.store((int)i); return; }   // (graph_is_chain and flatten_side disagree: cannot happen)
                 // LDS of one sweeping wavefront: W / Y history of hD steps x (64 lanes + 16 virtual lanes), X history of hDX
@@ -888,7 +904,10 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
         PgmJob &J = b->jobs[i];
         const Off &o = off[i];
         uint8_t *in = b->d_in, *w = b->d_work, *ob = b->d_out;
-        J.sites1 = (const double *)(in + o.s1.sites); J.sites2 = (const double *)(in + o.s2.sites);
+        J.sites1 = ref_of(res1, i) ? res1[i].dev_sites : (const double *)(in + o.s1.sites);
+        J.sites2 = ref_of(res2, i) ? res2[i].dev_sites : (const double *)(in + o.s2.sites);
+        J.smap1 = o.s1.has_smap ? (const uint32_t *)(in + o.s1.smap) : nullptr;
+        J.smap2 = o.s2.has_smap ? (const uint32_t *)(in + o.s2.smap) : nullptr;
         J.M = (const double *)(in + o.M); J.pi = (const double *)(in + o.pi);
         J.ni1 = (const PgmNode2 *)(in + o.s1.ni); J.ni2 = (const PgmNode2 *)(in + o.s2.ni);
         J.xp1 = (const int32_t *)(in + o.s1.xp); J.xp2 = (const int32_t *)(in + o.s2.xp);
@@ -1320,10 +1339,16 @@ int pgm_align_batch_test_stall(pgm_align_batch *b, uint32_t job, uint32_t band, 
 
 int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out) {
+    return pgm_align_graphs_batch_res(ctx, njobs, g1, g2, model, scores, nullptr, nullptr, out);
+}
+
+int pgm_align_graphs_batch_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
+                               const pgm_model *const *model, const pgm_scores *scores, const pgm_site_ref *res1, const pgm_site_ref *res2,
+                               pgm_align_out *out) {
     pgm_align_batch *b = nullptr;
     const bool prof = getenv("PGM_HOST_PROFILE") != nullptr;   // tools: where the time of one call goes
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = pgm_align_batch_create(ctx, njobs, g1, g2, model, scores, &b);
+    int rc = pgm_align_batch_create_res(ctx, njobs, g1, g2, model, scores, 0u, res1, res2, &b);
     if (rc != PGM_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
     rc = pgm_align_batch_run(ctx, b);

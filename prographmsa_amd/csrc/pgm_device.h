@@ -108,6 +108,7 @@ struct PgmJob {
 
     // inputs as uploaded
     const double *sites1, *sites2;   // dim x n column-major
+    const uint32_t *smap1, *smap2;   // profiles resident in HBM (pgm_site_ref): node i's column of sites is smap[i] (NULL: i)
     const double *M, *pi;            // dim x dim column-major, dim
     // per-node edge data prepared by the host from the CSR (costs are float32 as in Graph.h:223-239)
     const PgmNode2 *ni1, *ni2;       // near costs + far entries of every node

@@ -78,3 +78,83 @@ def test_merge_profiles_rejects_bad_mappings(ctx):
     j.sites1, j.sites2, j.P1, j.P2 = P(g, C.c_double), P(g, C.c_double), P(Pm, C.c_double), P(Pm, C.c_double)
     j.k1, j.k2, j.g2_with_P1, j.profiles = P(k1, C.c_uint32), P(k2, C.c_uint32), P(fl, C.c_uint8), P(out, C.c_double)
     assert pg.lib.pgm_merge_profiles_batch(ctx.handle, 1, C.byref(j)) == pg.PGM_ERR_INVALID
+
+
+def test_resident_profiles_through_merge_and_alignment(ctx):
+    """pgm_merge_profiles_batch_ex(PGM_MERGE_RESIDENT) leaves the merged profiles in HBM; a second merge reads them from there and
+    pgm_align_graphs_batch_res aligns graphs whose sites are those matrices gathered through a node map (a CleanedGraph): all
+    bit-identical to the path through the host."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    D = 20
+    rng = np.random.default_rng(77)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+
+    def merge_job(g1, g2, out):
+        n1, n2 = g1.shape[1], g2.shape[1]
+        k1, k2, fl = [], [], []
+        i1 = i2 = 0
+        while i1 < n1 or i2 < n2:
+            r = rng.random()
+            if i1 < n1 and i2 < n2 and r < 0.7:
+                k1.append(i1); k2.append(i2); fl.append(0); i1 += 1; i2 += 1
+            elif i1 < n1 and (r < 0.85 or i2 >= n2):
+                k1.append(i1); k2.append(GAP); fl.append(0); i1 += 1
+            else:
+                k1.append(GAP); k2.append(i2); fl.append(0); i2 += 1
+        k1 = np.array(k1, np.uint32); k2 = np.array(k2, np.uint32); fl = np.array(fl, np.uint8)
+        Pm = np.asfortranarray(np.eye(D) * 0.7 + 0.3 / D)
+        j = pg.pgm_merge_job()
+        j.dim, j.n1, j.n2, j.nnodes = D, n1, n2, len(k1)
+        j.P1, j.P2 = P(Pm, C.c_double), P(Pm, C.c_double)
+        j.k1, j.k2, j.g2_with_P1 = P(k1, C.c_uint32), P(k2, C.c_uint32), P(fl, C.c_uint8)
+        return j, (k1, k2, fl, Pm)
+
+    # two alignment jobs give four graphs; merge them pairwise, once through the host and once resident
+    js = [J.random_job(510 + i, n1, n2, skip_frac=0.2) for i, (n1, n2) in enumerate([(140, 150), (160, 130)])]
+    host_out, keep, mj = [], [], []
+    for j in js:
+        g1 = np.asfortranarray(j.g1.sites.reshape(j.g1.n, D).T.copy()) if j.g1.sites.ndim == 1 else np.asfortranarray(j.g1.sites)
+        g2 = np.asfortranarray(j.g2.sites.reshape(j.g2.n, D).T.copy()) if j.g2.sites.ndim == 1 else np.asfortranarray(j.g2.sites)
+        m, k = merge_job(g1, g2, None)
+        m.sites1, m.sites2 = P(g1, C.c_double), P(g2, C.c_double)
+        out = np.zeros(D * m.nnodes)
+        m.profiles = P(out, C.c_double)
+        mj.append(m); keep.append((g1, g2, k)); host_out.append(out)
+    arr = (pg.pgm_merge_job * 2)(*mj)
+    pg.check(pg.lib.pgm_merge_profiles_batch(ctx.handle, 2, arr))
+    dev = (C.POINTER(C.c_double) * 2)()
+    for m in mj:
+        m.profiles = None
+    arr = (pg.pgm_merge_job * 2)(*mj)
+    pg.check(pg.lib.pgm_merge_profiles_batch_ex(ctx.handle, 2, arr, pg.PGM_MERGE_RESIDENT, dev))
+    assert dev[0] and dev[1]
+    # (1) a merge whose inputs are the two resident matrices against the same merge from the host copies
+    h1 = np.asfortranarray(host_out[0].reshape(-1, D).T.copy()); h2 = np.asfortranarray(host_out[1].reshape(-1, D).T.copy())
+    m2, k2_ = merge_job(h1, h2, None)
+    want = np.zeros(D * m2.nnodes); got = np.zeros(D * m2.nnodes)
+    m2.sites1, m2.sites2, m2.profiles = P(h1, C.c_double), P(h2, C.c_double), P(want, C.c_double)
+    pg.check(pg.lib.pgm_merge_profiles_batch(ctx.handle, 1, C.byref(m2)))
+    m2.sites1, m2.sites2, m2.profiles = dev[0], dev[1], P(got, C.c_double)
+    pg.check(pg.lib.pgm_merge_profiles_batch(ctx.handle, 1, C.byref(m2)))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # (2) an alignment of "cleaned" versions of the two merged graphs: nodes picked by a map, chain edges; host sites against the
+    # resident matrices gathered through the same map
+    def cleaned(h, seed):
+        r = np.random.default_rng(seed)
+        n = h.shape[1]
+        keepn = np.sort(np.concatenate([[0], r.choice(np.arange(1, n - 1), size=(n - 2) * 3 // 4, replace=False), [n - 1]])).astype(np.uint32)
+        return keepn, np.asfortranarray(h[:, keepn])
+    map1, s1 = cleaned(h1, 1); map2, s2 = cleaned(h2, 2)
+    job = J.random_job(991, len(map1), len(map2), skip_frac=0.15)
+    job.g1.sites = np.ascontiguousarray(s1.T).reshape(-1) if job.g1.sites.ndim == 1 else s1
+    job.g2.sites = np.ascontiguousarray(s2.T).reshape(-1) if job.g2.sites.ndim == 1 else s2
+    ref = J.align_graphs_batch(ctx, [job])[0]
+    cj = J.CJobs([job])
+    r1 = (pg.pgm_site_ref * 1)(); r2 = (pg.pgm_site_ref * 1)()
+    r1[0].dev_sites, r1[0].node_map = dev[0], P(map1, C.c_uint32)
+    r2[0].dev_sites, r2[0].node_map = dev[1], P(map2, C.c_uint32)
+    pg.check(pg.lib.pgm_align_graphs_batch_res(ctx.handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out))
+    got = cj.results()[0]
+    assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
+    assert np.array_equal(got["map1"], ref["map1"]) and np.array_equal(got["map2"], ref["map2"])
