@@ -260,11 +260,13 @@ typedef struct pgm_merge_job {
 int pgm_merge_profiles_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs);
 /* The same with the results LEFT IN HBM (flags & PGM_MERGE_RESIDENT): dev_profiles[i] receives the device address of job i's
  * dim x nnodes matrix, jobs[i].profiles may be NULL and nothing is copied back; sites1 / sites2 of a job may themselves be such
- * addresses (the children's profiles never left the device).  The matrices of one call stay valid until the third-next resident
- * call on the context (a guide-tree level's graphs are read by the next level's alignments — pgm_site_ref — and merges only). */
+ * addresses (the children's profiles never left the device).  The matrices stay valid until pgm_resident_reset(ctx), which
+ * a caller issues at the start of a progressive pass (the memory is kept and handed out again); they are read by the
+ * alignments (pgm_site_ref) and merges of the levels above. */
 #define PGM_MERGE_RESIDENT 1u
 int pgm_merge_profiles_batch_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs, uint32_t flags,
                                 const double **dev_profiles);
+int pgm_resident_reset(pgm_ctx *ctx);
 float pgm_merge_last_kernel_ms(pgm_ctx *ctx);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ namespace {
 struct OracleBackend : Backend {
     const char *name() const override { return "oracle"; }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
-                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int) override {
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int, const pgm_site_ref *, const pgm_site_ref *) override {
         pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out);
     }
     // PGM_FARM_WORKERS=k: the farms of the host scaffolding (all-pairs tiles, jobs of a guide-tree level, leaves) run with k

@@ -48,7 +48,11 @@ struct pgm_ctx {
     int device = 0;
     PgmNwState *nw = nullptr;        // the all-pairs stage's two tiles in flight (pgm_nw_capi.inc)
     int nw_per_cu = 0;
-    uint32_t res_next = 0;           // resident merge results: next buffer of the ring (scratch slots 16..18)
+    // resident merge results (pgm_merge_profiles_batch_ex): bump allocation over chunks that live until pgm_resident_reset
+    // (a guide tree is not balanced: a level-1 graph may wait many levels for its sibling)
+    struct ResChunk { uint8_t *p; size_t cap; };
+    std::vector<ResChunk> res_chunks;
+    size_t res_chunk = 0, res_off = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
     hipStream_t stream3 = nullptr;   // ... and so does the band kernel (pgm_band_kernel)
@@ -239,6 +243,7 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     nw_state_free(ctx->nw);
+    for (auto &c : ctx->res_chunks) if (c.p) (void)hipFree(c.p);
     if (ctx->cs_lprofiles) (void)hipFree(ctx->cs_lprofiles);
     if (ctx->cs_centre) (void)hipFree(ctx->cs_centre);
     if (ctx->cs_priors) (void)hipFree(ctx->cs_priors);

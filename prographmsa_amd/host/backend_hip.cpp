@@ -39,9 +39,18 @@ struct HipBackend : Backend {
     const char *name() const override { return "hip"; }
     int workers() const override { return (int)ctxs.size(); }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
-                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int worker) override {
-        int rc = pgm_align_graphs_batch(ctx_of(worker), njobs, g1, g2, model, scores, out);
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int worker,
+                            const pgm_site_ref *res1, const pgm_site_ref *res2) override {
+        int rc = pgm_align_graphs_batch_res(ctx_of(worker), njobs, g1, g2, model, scores, res1, res2, out);
         if (rc != PGM_OK && rc != PGM_ERR_BACKTRACK) error("pgm_align_graphs_batch failed (%d): %s", rc, pgm_last_error());
+    }
+    // resident profiles: one context only (a parent's children would otherwise live on different devices), PGM_NO_RESIDENT switches it off
+    bool resident() const override { return ctxs.size() == 1 && !getenv("PGM_NO_RESIDENT"); }
+    void resident_reset() override { for (pgm_ctx *c : ctxs) (void)pgm_resident_reset(c); }
+    bool merge_profiles_batch_res(uint32_t njobs, const pgm_merge_job *jobs, const double **dev, int worker) override {
+        int rc = pgm_merge_profiles_batch_ex(ctx_of(worker), njobs, jobs, PGM_MERGE_RESIDENT, dev);
+        if (rc != PGM_OK) error("pgm_merge_profiles_batch_ex failed (%d): %s", rc, pgm_last_error());
+        return true;
     }
     int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq, const int8_t *syms,
                         const uint32_t *offs, uint32_t npairs, const uint32_t *pi, const uint32_t *pj, uint32_t flags, int32_t *counts,

@@ -35,8 +35,10 @@ Graph::Graph(int dim, const std::vector<std::vector<double>> &nodes, const EdgeM
 
 Graph::Graph(int dim, index_t n, const double *profiles, const std::vector<EdgeRec> &edges, const std::vector<RepeatRec> &repeats)
     : dim_(dim), n_(n) {
-    sites_.assign((size_t)dim * n_, 0.0);
-    if (n_ > 2) std::copy(profiles + dim, profiles + (size_t)dim * (n_ - 1), sites_.begin() + dim);
+    if (profiles) {   // (NULL: the profiles stay on the device, see devSites())
+        sites_.assign((size_t)dim * n_, 0.0);
+        if (n_ > 2) std::copy(profiles + dim, profiles + (size_t)dim * (n_ - 1), sites_.begin() + dim);
+    }
     e_rowptr_.assign(n_ + 1, 0);
     e_col_.resize(edges.size());
     e_val_.resize(edges.size());
@@ -124,7 +126,7 @@ pgm_graph Graph::flat() const {
     pgm_graph g;
     g.n = n_;
     g.dim = (uint32_t)dim_;
-    g.sites = sites_.data();
+    g.sites = sites_.empty() ? nullptr : sites_.data();
     g.e_rowptr = e_rowptr_.data();
     g.e_col = e_col_.data();
     g.e_val = e_val_.data();
@@ -227,11 +229,12 @@ CleanedGraph::CleanedGraph(const Graph &original) : Graph(original) {  // Cleane
     }
     for (index_t i = 0; i < newDim; ++i) rrp[i + 1] += rrp[i];
 
-    std::vector<double> newSites((size_t)dim_ * newDim, 0.0);
+    const bool host_sites = original.hasHostSites();   // (else: on the device, gathered there through outmapping_)
+    std::vector<double> newSites(host_sites ? (size_t)dim_ * newDim : 0, 0.0);
     outmapping_.assign(newDim, 0);
     for (index_t i = 0; i < n; ++i) {
         if (mapping[i] != (index_t)-1) {
-            std::copy(original.col(i), original.col(i) + dim_, newSites.begin() + (size_t)dim_ * mapping[i]);
+            if (host_sites) std::copy(original.col(i), original.col(i) + dim_, newSites.begin() + (size_t)dim_ * mapping[i]);
             outmapping_[mapping[i]] = i;
         }
     }

@@ -91,6 +91,7 @@ void set_job_dump(const std::string &path) {
     g_dump_path = path;
     if (!path.empty()) { FILE *f = fopen(path.c_str(), "wb"); if (f) fclose(f); }
 }
+bool job_dump_active() { return !g_dump_path.empty(); }
 static void dump_graph(FILE *f, const pgm_graph &g) {
     uint32_t hdr[4] = {g.n, g.dim, (uint32_t)g.e_rowptr[g.n], g.r_rowptr ? (uint32_t)g.r_rowptr[g.n] : 0u};
     fwrite(hdr, 4, 4, f);
@@ -143,7 +144,8 @@ void farm_run(const std::vector<std::vector<uint32_t>> &shards, const std::funct
 }
 
 std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1, const std::vector<const Graph *> &g2,
-                                              const std::vector<const Model *> &model) {
+                                              const std::vector<const Model *> &model, const std::vector<pgm_site_ref> &res1,
+                                              const std::vector<pgm_site_ref> &res2) {
     const uint32_t n = (uint32_t)g1.size();
     std::vector<pgm_graph> f1(n), f2(n);
     std::vector<pgm_model> fm(n);
@@ -169,7 +171,10 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
     });
     for (uint32_t i = 0; i < n; ++i) {
         be.cells_aligned += (uint64_t)(g1[i]->size() - 2) * (g2[i]->size() - 2);
-        if (!g_dump_path.empty()) dump_job(f1[i], f2[i], fm[i], sc[i]);
+        if (!g_dump_path.empty()) {
+            if (!f1[i].sites || !f2[i].sites) error("--dump_jobs needs the profiles on the host (PGM_NO_RESIDENT=1)");
+            dump_job(f1[i], f2[i], fm[i], sc[i]);
+        }
     }
     auto t0 = std::chrono::steady_clock::now();
     // The jobs of a level are independent (sibling subtrees, ProgressiveAlignment.cpp:50-51): with several device contexts
@@ -178,8 +183,9 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
     for (uint32_t i = 0; i < n; ++i) cost[i] = (uint64_t)g1[i]->size() * g2[i]->size();
     const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
     if (shards.size() <= 1) {
-        be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data(), 0);
+        be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data(), 0, res1.empty() ? nullptr : res1.data(), res2.empty() ? nullptr : res2.data());
     } else {
+        if (!res1.empty() || !res2.empty()) error("alignGraphsBatch: profiles resident on one device cannot be dealt to several");
         farm_run(shards, [&](int w) {
             const std::vector<uint32_t> &sh = shards[(size_t)w];
             const uint32_t m = (uint32_t)sh.size();
@@ -284,7 +290,7 @@ void mergeProfilesHost(const Graph &g1, const Graph &g2, const Model &model1, co
     }
 }
 
-AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const std::vector<double> &profiles,
+AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const double *profiles,
                             double support1, double support2) {
     const int D = g1.dim();
     const index_t NONE = (index_t)-1;
@@ -367,7 +373,7 @@ AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &p
             if (w == 0 || repeats[w - 1].to != repeats[k].to || repeats[w - 1].from != repeats[k].from) repeats[w++] = repeats[k];
         repeats.resize(w);
     }
-    result.graph = Graph(D, (index_t)nnodes, profiles.data(), edges, repeats);
+    result.graph = Graph(D, (index_t)nnodes, profiles, edges, repeats);
     return result;
 }
 
@@ -377,7 +383,7 @@ AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<
     const MergePlan plan = planMerge(g1, g2, mapping1, mapping2);
     std::vector<double> profiles;
     mergeProfilesHost(g1, g2, model1, model2, plan, profiles);
-    return finishMerge(g1, g2, plan, profiles, support1, support2);
+    return finishMerge(g1, g2, plan, profiles.data(), support1, support2);
 }
 
 }  // namespace pgm

@@ -144,6 +144,12 @@ public:
     int dim() const { return dim_; }
     const double *col(index_t i) const { return &sites_[(size_t)dim_ * i]; }
     const std::vector<double> &getSites() const { return sites_; }
+    // A merged graph whose profiles were left on the device (Backend::merge_profiles_batch_res) has no host copy of them
+    // (sites_ empty): devSites() is the dim x n matrix in HBM.  A CleanedGraph of such a graph refers to the same matrix
+    // through its node mapping (nodeMap()).
+    const double *devSites() const { return dev_sites_; }
+    void setDevSites(const double *p) { dev_sites_ = p; }
+    bool hasHostSites() const { return !sites_.empty(); }
     pgm_graph flat() const;  // view for the C ABI (valid while *this is alive and unchanged)
 
     // PredIterator (Graph.h:180-248)
@@ -177,6 +183,7 @@ public:
 private:
     int dim_;
     index_t n_;
+    const double *dev_sites_ = nullptr;
     std::vector<double> sites_;  // dim x n column-major
     std::vector<int32_t> e_rowptr_;
     std::vector<uint32_t> e_col_;
@@ -196,6 +203,7 @@ class CleanedGraph : public Graph {
 public:
     explicit CleanedGraph(const Graph &original);
     index_t getMapping(index_t i) const { return outmapping_[i]; }
+    const index_t *nodeMap() const { return outmapping_.data(); }   // node of the cleaned graph -> node of the original
     void uncleanMapping(std::vector<index_t> &mapping) const;
 private:
     std::vector<index_t> outmapping_;
@@ -225,9 +233,15 @@ struct Backend {
     // Every batch call takes the worker (device context) it runs on, 0 <= worker < workers(); calls with different workers may
     // run concurrently.  The host code shards a batch's independent units over the workers (farm_shards below): jobs of a
     // guide-tree level, leaves, merges, sequence pairs — no exchange between workers, results independent of their number.
+    // res1 / res2 (may be NULL): graphs whose profiles the device already holds (include/pgm_hip.h: pgm_site_ref)
     virtual void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                                     const pgm_model *const *model, const pgm_scores *scores,
-                                    pgm_align_out *out, int worker = 0) = 0;
+                                    pgm_align_out *out, int worker = 0, const pgm_site_ref *res1 = nullptr, const pgm_site_ref *res2 = nullptr) = 0;
+    // the merged graphs' profiles may stay on the device between the levels of a progressive pass (one context, nobody reads
+    // them on the host): merge_profiles_batch_res leaves them there and returns their device addresses
+    virtual bool resident() const { return false; }
+    virtual void resident_reset() {}   // start of a progressive pass: the previous pass's device-resident profiles are dead
+    virtual bool merge_profiles_batch_res(uint32_t, const pgm_merge_job *, const double **, int = 0) { return false; }
     // One tile of alignPair jobs in two halves (include/pgm_hip.h: pgm_nw_pairs_submit / pgm_nw_pairs_wait): a worker keeps two
     // tiles in flight.  flags & PGM_NW_REDUCED: counts = (ident, total) per pair.  Result buffers come from host_alloc.
     virtual int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
@@ -263,13 +277,17 @@ std::vector<std::vector<uint32_t>> farm_shards(const std::vector<uint64_t> &cost
 // runs fn(w) for every non-empty shard, worker 0 on the calling thread, the others on threads of their own
 void farm_run(const std::vector<std::vector<uint32_t>> &shards, const std::function<void(int)> &fn);
 void set_job_dump(const std::string &path);  // if set, every alignGraphs job is appended to this file
+bool job_dump_active();
 void set_dist_dump(const std::string &path); // if set, every distance matrix TreeNJ estimates is appended (dim, D, V as raw doubles)
 
 // alignGraphs (GraphAlign.h:200-534): one job; and the batched form the scheduler uses.
 AlignmentResult alignGraphs(const Graph &g1, const Graph &g2, const Model &model);
+// (res1 / res2: per job, where the device holds the graphs' profiles — empty vectors or entries with dev_sites == NULL: nowhere)
 std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1,
                                               const std::vector<const Graph *> &g2,
-                                              const std::vector<const Model *> &model);
+                                              const std::vector<const Model *> &model,
+                                              const std::vector<pgm_site_ref> &res1 = std::vector<pgm_site_ref>(),
+                                              const std::vector<pgm_site_ref> &res2 = std::vector<pgm_site_ref>());
 // mergeGraphs (GraphAlign.h:550-727)
 // mergeGraphs in three parts, so that the profiles of all merges of a guide-tree level can be computed in one device batch:
 //   planMerge     the "unify" walk over the two mappings (GraphAlign.h:569-620 without the arithmetic): per node of the
@@ -284,7 +302,7 @@ struct MergePlan {
 MergePlan planMerge(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1, const std::vector<index_t> &mapping2);
 void mergeProfilesHost(const Graph &g1, const Graph &g2, const Model &model1, const Model &model2, const MergePlan &plan,
                        std::vector<double> &profiles);   // dim x nnodes column-major
-AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const std::vector<double> &profiles,
+AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &plan, const double *profiles /* NULL: they stay on the device */,
                             double support1, double support2);
 AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
                             const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,

@@ -202,6 +202,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                                                  const ModelFactory &model_factory,
                                                  const std::map<std::string, std::vector<repeat_t>> *repeats) {
     const auto tl0 = std::chrono::steady_clock::now();
+    default_backend().resident_reset();   // (merged profiles a previous pass left on the device)
     std::vector<Node> nodes;
     int root = collect(tree, nodes);
     int maxh = nodes[root].height;
@@ -336,19 +337,36 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         std::vector<const Graph *> g1(L), g2(L);
         std::vector<const Model *> mm(L);
         for (size_t k = 0; k < L; ++k) { g1[k] = pend[k].cg1.get(); g2[k] = pend[k].cg2.get(); mm[k] = &pend[k].model; }
-        std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm);
+        // graphs merged on the device one level below: their profiles never left it (gathered there through the cleaned graphs' node maps)
+        std::vector<pgm_site_ref> rs1, rs2;
+        {
+            bool any = false;
+            for (size_t k = 0; k < L; ++k) any = any || pend[k].cg1->devSites() || pend[k].cg2->devSites();
+            if (any) {
+                rs1.assign(L, pgm_site_ref{nullptr, nullptr}); rs2.assign(L, pgm_site_ref{nullptr, nullptr});
+                for (size_t k = 0; k < L; ++k) {
+                    if (pend[k].cg1->devSites()) rs1[k] = pgm_site_ref{pend[k].cg1->devSites(), pend[k].cg1->nodeMap()};
+                    if (pend[k].cg2->devSites()) rs2[k] = pgm_site_ref{pend[k].cg2->devSites(), pend[k].cg2->nodeMap()};
+                }
+            }
+        }
+        std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm, rs1, rs2);
         const auto tp2 = std::chrono::steady_clock::now();
         // mergeGraphs of the whole level: plans on host threads, the node profiles (P g products, L2 normalisation: the
         // arithmetic of the merge) in ONE device batch, then edges / Graph / extend_alignment on host threads again
         std::vector<MergePlan> plans(L);
         std::vector<std::vector<double>> profiles(L);
+        // The merged profiles stay on the device when nothing on the host reads them: one device context, no --profile_out /
+        // --ancestral_seqs, no job dump (Backend::resident; PGM_NO_RESIDENT=1 keeps the round trip)
+        const bool resident = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active();
+        std::vector<const double *> dev_profiles(L, nullptr);
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             Pending &p = pend[k];
             p.cg1->uncleanMapping(ar[k].mapping1);
             p.cg2->uncleanMapping(ar[k].mapping2);
             plans[k] = planMerge(nodes[nd.child[0]].res.graph, nodes[nd.child[1]].res.graph, ar[k].mapping1, ar[k].mapping2);
-            profiles[k].assign((size_t)a.DIM * plans[k].mapping1.size(), 0.0);
+            if (!resident) profiles[k].assign((size_t)a.DIM * plans[k].mapping1.size(), 0.0);
         });
         const auto tq0 = std::chrono::steady_clock::now();
         bool on_device = false;
@@ -359,10 +377,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 const Graph &ga = nodes[nd.child[0]].res.graph, &gb = nodes[nd.child[1]].res.graph;
                 pgm_merge_job &j = mj[k];
                 j.dim = (uint32_t)a.DIM; j.n1 = ga.size(); j.n2 = gb.size(); j.nnodes = (uint32_t)plans[k].mapping1.size();
-                j.sites1 = ga.col(0); j.sites2 = gb.col(0);
+                j.sites1 = ga.devSites() ? ga.devSites() : ga.col(0); j.sites2 = gb.devSites() ? gb.devSites() : gb.col(0);
                 j.P1 = pend[k].model1.P.data(); j.P2 = pend[k].model2.P.data();
                 j.k1 = plans[k].mapping1.data(); j.k2 = plans[k].mapping2.data(); j.g2_with_P1 = plans[k].g2_with_P1.data();
-                j.profiles = profiles[k].data();
+                j.profiles = resident ? nullptr : profiles[k].data();
             }
             const auto tm0 = std::chrono::steady_clock::now();
             {
@@ -371,7 +389,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 std::vector<uint64_t> cost(L);
                 for (size_t k = 0; k < L; ++k) cost[k] = mj[k].nnodes;
                 const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
-                if (shards.size() <= 1) {
+                if (resident) {
+                    on_device = be.merge_profiles_batch_res((uint32_t)L, mj.data(), dev_profiles.data(), 0);
+                    if (!on_device) error("the backend could not keep the merged profiles on the device");
+                } else if (shards.size() <= 1) {
                     on_device = be.merge_profiles_batch((uint32_t)L, mj.data(), 0);
                 } else {
                     std::vector<char> ok(shards.size(), 0);
@@ -397,8 +418,9 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             result.is_csprofile = false;
             result.n_tr_indels = ar[k].n_tr_indels + r1.n_tr_indels + r2.n_tr_indels;
             if (!on_device) mergeProfilesHost(r1.graph, r2.graph, p.model1, p.model2, plans[k], profiles[k]);
-            AncestralResult anc = finishMerge(r1.graph, r2.graph, plans[k], profiles[k], (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
+            AncestralResult anc = finishMerge(r1.graph, r2.graph, plans[k], resident ? nullptr : profiles[k].data(), (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
             result.graph = anc.graph;
+            if (resident) result.graph.setDevSites(dev_profiles[k]);
             extend_alignment(a, result, anc.mapping1, r1.aligned_sequences, L == 1);
             extend_alignment(a, result, anc.mapping2, r2.aligned_sequences, L == 1);
             if (!r1.tr_homologies.empty() || !r2.tr_homologies.empty()) {   // ProgressiveAlignment.h:455-456, 468
