@@ -267,6 +267,12 @@ int pgm_merge_profiles_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *
 int pgm_merge_profiles_batch_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_merge_job *jobs, uint32_t flags,
                                 const double **dev_profiles);
 int pgm_resident_reset(pgm_ctx *ctx);
+/* The leaf graphs of a pass built in HBM — replaces the profile matrix of reference src/SequenceGraph.h:101-109 for nseq
+ * sequences: syms = ALPHABET::value() per residue, negative for a residue without a value (uniform 1 / dim column); dev[s]
+ * receives the device address of sequence s's dim x (L + 2) matrix (START and END columns zero), valid until
+ * pgm_resident_reset.  Used through pgm_site_ref and as sites1 / sites2 of pgm_merge_profiles_batch_ex. */
+int pgm_resident_onehot(pgm_ctx *ctx, uint32_t dim, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
+                        const double **dev);
 float pgm_merge_last_kernel_ms(pgm_ctx *ctx);
 
 #ifdef __cplusplus

@@ -1064,7 +1064,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
             band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.75 * t_goal))));
             if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
             else if (total != 0)
-                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.75 * t_goal) band_cus += std::max(1u, band_cus / 16u);
+                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.75 * t_goal) band_cus += std::max(1u, band_cus / 8u);   // (a simulation of a 1000-band list is 0.1 ms: few of them)
             else band_cus = most;
             band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
             band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);

@@ -78,4 +78,22 @@ __global__ void __launch_bounds__(256) pgm_merge_profiles_kernel(const PgmMergeJ
     }
 }
 
+// Leaf graphs of a progressive pass built where they are used (SequenceGraph.h:101-109): column c of sequence s's dim x (L + 2)
+// profile matrix is zero for START / END, one-hot for a residue with a value, uniform 1 / dim for one without (sym < 0).
+__global__ void __launch_bounds__(256) pgm_onehot_kernel(uint32_t dim, uint32_t nseq, const int8_t *__restrict__ syms, const uint32_t *__restrict__ offs,
+                                                       const uint64_t *__restrict__ col0, double *__restrict__ out, uint64_t ncols) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (c >= ncols) return;
+    // which sequence: col0[s] <= c < col0[s + 1] (binary search, nseq is small)
+    uint32_t lo = 0, hi = nseq;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (col0[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t s = lo, L = offs[s + 1] - offs[s];
+    const uint64_t k = c - col0[s];
+    double *dst = out + c * dim;
+    int sym = -2;   // START / END
+    if (k >= 1 && k <= L) sym = syms[offs[s] + (uint32_t)(k - 1)];
+    const double uni = 1.0 / (double)dim;
+    for (uint32_t r = 0; r < dim; ++r) dst[r] = sym == -2 ? 0.0 : (sym < 0 ? uni : ((uint32_t)sym == r ? 1.0 : 0.0));
+}
+
 #endif

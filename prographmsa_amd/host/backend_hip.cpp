@@ -46,6 +46,11 @@ struct HipBackend : Backend {
     }
     // resident profiles: one context only (a parent's children would otherwise live on different devices), PGM_NO_RESIDENT switches it off
     bool resident() const override { return ctxs.size() == 1 && !getenv("PGM_NO_RESIDENT"); }
+    bool resident_onehot(uint32_t dim, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double **dev, int worker) override {
+        int rc = pgm_resident_onehot(ctx_of(worker), dim, nseq, syms, offs, dev);
+        if (rc != PGM_OK) error("pgm_resident_onehot failed (%d): %s", rc, pgm_last_error());
+        return true;
+    }
     void resident_reset() override { for (pgm_ctx *c : ctxs) (void)pgm_resident_reset(c); }
     bool merge_profiles_batch_res(uint32_t njobs, const pgm_merge_job *jobs, const double **dev, int worker) override {
         int rc = pgm_merge_profiles_batch_ex(ctx_of(worker), njobs, jobs, PGM_MERGE_RESIDENT, dev);

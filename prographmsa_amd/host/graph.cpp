@@ -58,6 +58,12 @@ Graph::Graph(int dim, index_t n, const double *profiles, const std::vector<EdgeR
     for (index_t i = 0; i < n_; ++i) { e_rowptr_[i + 1] += e_rowptr_[i]; r_rowptr_[i + 1] += r_rowptr_[i]; }
 }
 
+Graph::Graph(int dim, index_t n, NoSites) : dim_(dim), n_(n) {
+    e_rowptr_.assign(n_ + 1, 0);
+    r_rowptr_.assign(n_ + 1, 0);
+    fillInitialEdges();
+}
+
 void Graph::fillInitialEdges() {  // chain edges (i+1 <- i) with stored value -MAX_EDGE_COST (cost 0)
     e_rowptr_.assign(n_ + 1, 0);
     e_col_.clear();

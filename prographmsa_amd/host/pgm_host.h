@@ -139,6 +139,9 @@ public:
     struct EdgeRec { index_t to, from; dp_score_t cost; };
     struct RepeatRec { index_t to, from, units; };
     Graph(int dim, index_t n, const double *profiles, const std::vector<EdgeRec> &edges, const std::vector<RepeatRec> &repeats);
+    // a chain of n nodes whose profiles live on the device only (a leaf graph of a resident pass: setDevSites)
+    struct NoSites {};
+    Graph(int dim, index_t n, NoSites);
 
     index_t size() const { return n_; }
     int dim() const { return dim_; }
@@ -240,6 +243,7 @@ struct Backend {
     // the merged graphs' profiles may stay on the device between the levels of a progressive pass (one context, nobody reads
     // them on the host): merge_profiles_batch_res leaves them there and returns their device addresses
     virtual bool resident() const { return false; }
+    virtual bool resident_onehot(uint32_t, uint32_t, const int8_t *, const uint32_t *, const double **, int = 0) { return false; }   // leaf graphs built on the device
     virtual void resident_reset() {}   // start of a progressive pass: the previous pass's device-resident profiles are dead
     virtual bool merge_profiles_batch_res(uint32_t, const pgm_merge_job *, const double **, int = 0) { return false; }
     // One tile of alignPair jobs in two halves (include/pgm_hip.h: pgm_nw_pairs_submit / pgm_nw_pairs_wait): a worker keeps two

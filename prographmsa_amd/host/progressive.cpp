@@ -213,6 +213,11 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         if (nodes[i].tree->isLeaf()) leaves.push_back((int)i);
     for (int li : leaves)
         if (sequences.find(nodes[li].tree->getName()) == sequences.end()) error("unknown sequence name: %s", nodes[li].tree->getName().c_str());
+    // A pass whose merged profiles stay on the device (see the level loop) builds its leaf graphs there too: the host keeps
+    // their edges only (SequenceGraph's profile matrix is 160 bytes per residue: 41 MB for 256 x 1000, otherwise built here,
+    // copied into the staging block and uploaded for the alignments, and once more for the merges)
+    const bool resident_pass = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active();
+    const bool resident_leaves = resident_pass && !csprofile;
     parallel_for(leaves.size(), [&](size_t k) {   // (independent leaves: a thousand SequenceGraphs are 50 ms on one thread)
         Node &nd = nodes[leaves[k]];
         auto it = sequences.find(nd.tree->getName());
@@ -220,7 +225,9 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         nd.res.score = 0;
         nd.res.n_tr_indels = 0;
         nd.res.is_csprofile = false;
-        if (!csprofile) {
+        if (resident_leaves) {
+            nd.res.graph = Graph(a.DIM, (index_t)it->second.size() + 2, Graph::NoSites());
+        } else if (!csprofile) {
             nd.res.graph = SequenceGraph(a, it->second);
             if (!cmdlineopts.profile_file.empty()) {   // result.profiles[name] = sites without START / END (ProgressiveAlignment.h:73)
                 Profile &pf = nd.res.profiles[it->first];
@@ -229,6 +236,18 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             }
         }
     });
+    if (resident_leaves && !leaves.empty()) {
+        std::vector<int8_t> syms;
+        std::vector<uint32_t> offs(leaves.size() + 1, 0);
+        for (size_t s = 0; s < leaves.size(); ++s) {
+            const sequence_t &seq = sequences.at(nodes[leaves[s]].tree->getName());
+            for (int8_t c : seq) syms.push_back(a.isValid(c) ? (int8_t)a.value(c) : (int8_t)-1);
+            offs[s + 1] = (uint32_t)syms.size();
+        }
+        std::vector<const double *> dev(leaves.size(), nullptr);
+        if (!default_backend().resident_onehot((uint32_t)a.DIM, (uint32_t)leaves.size(), syms.data(), offs.data(), dev.data(), 0)) error("the backend could not build the leaf graphs on the device");
+        for (size_t s = 0; s < leaves.size(); ++s) nodes[leaves[s]].res.graph.setDevSites(dev[s]);
+    }
     if (csprofile) {
         // SequenceGraph(seq, csprofile, model_factory.getModel(branch_length)) for every leaf in one
         // createProfile batch (SequenceGraph.h:111-121, CSProfile.cpp:175-225).
@@ -358,7 +377,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         std::vector<std::vector<double>> profiles(L);
         // The merged profiles stay on the device when nothing on the host reads them: one device context, no --profile_out /
         // --ancestral_seqs, no job dump (Backend::resident; PGM_NO_RESIDENT=1 keeps the round trip)
-        const bool resident = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active();
+        const bool resident = resident_pass;
         std::vector<const double *> dev_profiles(L, nullptr);
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
