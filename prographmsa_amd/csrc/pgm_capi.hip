@@ -1061,11 +1061,16 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         double band_end = 0.0;
         if (total_b != 0) {
             const uint32_t most = total != 0 ? capacity - 1u : capacity;
-            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.75 * t_goal))));
+            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.75 * t_goal)) + 1u));
             if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
-            else if (total != 0)
-                while (band_cus < most && (band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands)) > 0.75 * t_goal) band_cus += std::max(1u, band_cus / 8u);   // (a simulation of a 1000-band list is 0.1 ms: few of them)
-            else band_cus = most;
+            else if (total != 0) {
+                // (a simulation of a 1000-band list is 0.1 ms: the share is scaled by how far the schedule overshoots, three times at most)
+                for (int it = 0; it < 3 && band_cus < most; ++it) {
+                    band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
+                    if (band_end <= 0.75 * t_goal) break;
+                    band_cus = std::min(most, std::max(band_cus + 1u, (uint32_t)std::ceil(band_cus * std::min(2.0, band_end / (0.75 * t_goal)))));
+                }
+            } else band_cus = most;
             band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
             band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
             capacity = std::max(1u, capacity - band_cus);
