@@ -950,6 +950,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
             // (pgm_prelink_tile): it then copies that tile's table (6 KB) and follows its links from grid tile to grid tile — one
             // flag and one table round trip per tile, no staging, no link pass — until it meets a cell without a link or a tile
             // that is not ready, and goes on there as before.
+            bool nolink = false;
             if (reload && J.lrows != 0u && !(y == nl_y && x == nl_x)) {
                 bool moved = false;
                 uint32_t st = (uint32_t)(current_state == State_m ? 0 : (current_state == State_x ? 1 : 2));
@@ -985,7 +986,7 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                         const uint32_t j = (x >> 5) - first;
                         if (j >= gw) break;
                         const uint32_t code = tab[j * PGM_LK_TAB + st * (TT * TT) + (y & 31u) * TT + (x & 31u)];
-                        if (!(code & 0x8000u)) break;
+                        if (!(code & 0x8000u)) { nolink = true; break; }
                         y -= (code >> 6) & 63u; x -= code & 63u; st = (code >> 12) & 3u;
                         moved = true;
                         if ((y | x) == 0u) break;
@@ -1004,7 +1005,10 @@ __device__ static void pgm_traceback_job(const PgmJob &J, PgmTbLds &T, const int
                 }
                 nl_y = y; nl_x = x;   // nothing to follow from here: decide this cell the usual way, then look again
             }
-            if (reload) {
+            // A cell without a link inside a pre-linked row (a predecessor beyond the halo, more than eight predecessors, a repeat
+            // edge): the general code below decides it from memory, and the walk goes on in the pre-linked rows — staging and
+            // linking a tile of the walker's own for that one cell costs twice as much
+            if (reload && !(nolink && y == nl_y && x == nl_x)) {
                 ty0 = y >= TT - 1 ? y - (TT - 1) : 0u;
                 tx0 = x >= TT - 1 ? x - (TT - 1) : 0u;
                 const unsigned long long r0 = stat ? __builtin_amdgcn_s_memrealtime() : 0ull;
