@@ -218,7 +218,10 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     {   // (the launch of the longest chains on the highest stream priority the device offers)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-        HIPCHK(hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, hi));
+        if (hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, hi) != hipSuccess) {   // (no priorities: an ordinary stream)
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking));
+        }
     }
     hipLaunchKernelGGL(pgm_warm_kernel, dim3(1), dim3(64), 0, c->stream);
     HIPCHK(hipGetLastError());
