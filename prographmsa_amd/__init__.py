@@ -62,7 +62,7 @@ class pgm_align_out(C.Structure):
 EXPORTS = [
     "pgm_device_count", "pgm_ctx_create", "pgm_ctx_destroy", "pgm_last_error", "pgm_ctx_device_info",
     "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_create_res", "pgm_align_graphs_batch_res", "pgm_align_batch_run", "pgm_align_batch_fetch",
-    "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_align_batch_stage_times", "pgm_align_batch_job_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
+    "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_test_cu_shares", "pgm_align_batch_stage_times", "pgm_align_batch_job_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
     "pgm_merge_profiles_batch", "pgm_merge_profiles_batch_ex", "pgm_resident_reset", "pgm_resident_onehot", "pgm_merge_last_kernel_ms",
@@ -92,6 +92,7 @@ def _load():
         "pgm_align_batch_destroy": (None, [vp, vp]),
         "pgm_align_batch_cells": (C.c_uint64, [vp]),
         "pgm_align_batch_test_stall": (C.c_int, [vp, u32, u32, u32]),
+        "pgm_test_cu_shares": (C.c_int, [u32, C.c_double, u32, C.c_double, u32, C.c_double, u32, u32, C.c_double, C.POINTER(C.c_uint32)]),
         "pgm_align_batch_stage_times": (C.c_int, [vp, C.c_int] + [C.POINTER(C.c_float)] * 3 + [C.POINTER(u32)]),
         "pgm_align_batch_job_times": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "pgm_align_batch_time": (C.c_int, [vp, vp, C.c_int] + [C.POINTER(C.c_float)] * 4),

@@ -2322,7 +2322,10 @@ __device__ static void pgm_traceback_chain(const PgmJob &J, uint8_t *pool, uint3
 // Columns with more on-chip entries than the summary holds keep the rest in an overflow table (LDS copy, any helper).
 template <int GROUP, bool LONG, bool MASK = false>   // MASK: the column summaries of this job may hold long entries in their last slots
 __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *sw_generic,
-                                                 const int hidx, const uint32_t part, const uint32_t nparts, const bool idle = false, const bool nofold = false, unsigned long long *hst = nullptr) {
+                                                 const int hidx, const uint32_t part, const uint32_t nparts, const bool idle = false, const bool nofold = false, unsigned long long *hst = nullptr,
+                                                 const uint32_t tpar = 0u, const uint32_t tstr = 1u, const int flag_idx = 8, float *sblk_own = nullptr, const bool builder = true) {
+    // (tpar, tstr: the steps this wavefront evaluates, t % tstr == tpar — pgm_crit_kernel deals the steps of a band to two wavefronts
+    // per part; flag_idx: the word "row entry list built"; sblk_own: this wavefront's score block; builder: part 0 builds the list)
     constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, KF = PGM_KF8, RS = 5, PF = PGM_PF, NL = PGM_NLONG, KQ = 3;
     static_assert(PF == 4 && BL == 8, "FIFO slots are indexed with i & 3");
     static_assert(PGM_DCAP + 1 - (4 + PF) >= 16 + 3, "a long source must be stored before the sweep's last counted wait");
@@ -2338,7 +2341,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     const float *hW = (const float *)slot, *hY = hW + D * HS, *hX = hY + D * HS;
     const float4 *ring3 = (const float4 *)(hX + DX * 64u);
     uint8_t *aux = slot + J.aux_off;
-    float *res = (float *)(aux + PGM_AUX_RES), *sblk = (float *)(aux + PGM_AUX_SBLK) + part * 512u;
+    float *res = (float *)(aux + PGM_AUX_RES), *sblk = sblk_own ? sblk_own : (float *)(aux + PGM_AUX_SBLK) + part * 512u;
     uint2 *elist = (uint2 *)(aux + PGM_AUX_EL);
     int *ecnt = (int *)(aux + PGM_AUX_CNT);
     uint2 *ovtab = (uint2 *)(slot + J.ov_off);
@@ -2382,7 +2385,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
     bool e_ok[KQ], e_rem = false;
     uint32_t e_off = 0u;
     if (GROUP == 2) {
-        if (part == 0u) {
+        if (part == 0u && builder) {
             __hip_atomic_store(ecnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(ecnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const int32_t f0 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc) : 0, f1 = (rowvalid && !geny) ? pgm_gld(J.fp1 + yc + 1) : 0;
@@ -2399,9 +2402,9 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                 if (pos < 512u) elist[pos] = make_uint2((uint32_t)lane | ((dx & 0x7fffffu) << 8) | (dx & 0x80000000u), cb);
             }
             asm volatile("" ::: "memory");
-            __hip_atomic_store(sw + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(sw + flag_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(2);
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(sw + flag_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(2);
             asm volatile("" ::: "memory");
         }
         const int totR = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ecnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -2506,6 +2509,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
         load_s_block(t0 + BL);
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
+            if (!LONG && tstr == 2u && ((uint32_t)i & 1u) != tpar) continue;   // (the other wavefront of this part takes that step)
             const uint32_t t = t0 + (uint32_t)i;
             const int need = max(1, (int)t - slack + 2);
             while (seen < need) {   // (a sleeping poll: a tight one would keep the CU's LDS pipeline and this SIMD's issue slots busy;

@@ -21,6 +21,7 @@
 #include <sys/mman.h>
 
 #include "pgm_align_kernels.h"
+#include "pgm_crit_kernels.h"
 #include "pgm_nw_kernels.h"
 #include "pgm_csprofile_kernels.h"
 #include "pgm_dist_kernels.h"
@@ -168,6 +169,7 @@ struct pgm_align_batch {
     PgmItem *d_bands = nullptr;
     unsigned long long *d_times = nullptr;   // per job {last band complete, traceback published}, then the launch's start (ticks of 10 ns)
     hipEvent_t ev_join_b = nullptr;
+    bool crit_c3 = false, rest_c3 = false;   // every item of the launch for the longest chains / of the main launch belongs to a crit3 job: pgm_crit_kernel sweeps that list
     uint32_t ncrit = 0, ncrit_workers = 0, ntb_c = 0;   // the first ncrit items of the work list: the jobs with the longest chains, swept by a launch of their own on their own CUs; their tracebacks
     hipEvent_t ev_join_c = nullptr;
     uint32_t ntb_b = 0, ntb_b_workers = 0;          // ... of the jobs pgm_band_kernel sweeps: their instance of pgm_tb_kernel follows it on its stream
@@ -287,6 +289,7 @@ struct SideOff {
     uint32_t far_dmin;            // smallest distance of a far entry (PGM_DCAP + 1 if there is none)
     uint32_t remote;              // MODE 2: entries served from the cell storage by the far helpers
     uint32_t nov;                 // MODE 2, columns: records of the overflow table in use
+    uint32_t ngeneric;            // nodes served by the generic path
     // host only: far candidates (every finite edge outside the near slots) of node v: [cp[v], cp[v+1])
     std::vector<uint32_t> cp, cd;
     std::vector<float> cv;
@@ -384,7 +387,7 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
     int32_t *fp = (int32_t *)(base + o.fp);
     uint2 *fe = (uint2 *)(base + o.fe), *ov = (uint2 *)(base + o.ov);
     o.nov = 0;
-    o.far_nodes = 0; o.maxd = 1; o.far_dmin = PGM_DCAP + 1; o.remote = 0;
+    o.far_nodes = 0; o.maxd = 1; o.far_dmin = PGM_DCAP + 1; o.remote = 0; o.ngeneric = 0;
     uint32_t band_entries = 0, band_remote = 0, nfe = 0;
     fp[0] = 0;
     for (uint32_t v = 0; v < n; ++v) {
@@ -440,6 +443,7 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
             I.c2 = I.c3 = INFINITY;
             for (int k = 0; k < PGM_KF8; ++k) { I.fd[k] = 0; I.fc[k] = INFINITY; }
             I.flags = PGM_NF_GENERIC | (1u << 8) | kill;
+            ++o.ngeneric;
         } else {
             const bool rows2 = mode2 && side == 0;
             I.flags = (rows2 ? 0u : nloc) | (dmax << 8) | kill | ((mode2 && side == 1) ? (nrem << 16) | (novf << 20) | (ovi << 25) : 0u);
@@ -565,6 +569,52 @@ static hipError_t scratch_events(pgm_ctx *ctx) {
     return hipSuccess;
 }
 
+// How the CUs of the device are dealt to the four sweep launches of a batch (pure arithmetic; pgm_test_cu_shares exports it for
+// the CPU tests).  Every launch is a grid of persistent workers, one per CU, and all four are resident together (no grid ever
+// waits for a CU), so the shares add up to at most `cus` and every queue with work gets at least one CU.
+//   crit   the launch of the longest chains: one CU per band, at most half of the device, and only if it leaves every other
+//          queue with work at least one CU (else 0: the caller leaves those jobs in the main launch)
+//   then the time to beat is t_goal = max(longest chain of sweeps, all other work / the other CUs).  A batch bound by that chain
+//   (chain >= 1.5 x the parallel time) wants the other launches' traffic out of the chain's way early: the lean queue gets the
+//   fewest CUs with which it ends within 0.6 t_goal, the band queue within 0.75 t_goal (measured on the headline batch, round 3);
+//   a batch bound by throughput wants every queue to end together: the factors go to 1 as the chain's lead shrinks to nothing.
+//   rest   the main launch: what is left, never less than its own work needs to end within t_goal — if the three shares do not fit,
+//          they are cut back in proportion to their work.
+struct CuShares { uint32_t lean, band, crit, rest, rest_need; double t_goal, fl, fb; };
+static CuShares cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost, uint32_t nrest, uint32_t ncrit, double rsweep) {
+    CuShares r = {0u, 0u, 0u, 0u, 0u, 0.0, 1.0, 1.0};
+    cus = std::max(1u, cus);
+    const uint32_t queues = (nlean != 0) + (nbands != 0) + (nrest != 0);
+    if (ncrit != 0 && cus > queues) r.crit = std::min(std::min(ncrit, cus / 2u), cus - queues);
+    const uint32_t cap = std::max(1u, cus - r.crit);
+    const double sum = (nlean ? lean_cost : 0.0) + (nbands ? band_cost : 0.0) + (nrest ? rest_cost : 0.0);
+    const double t_par = std::max(1e-3, sum / cap);
+    r.t_goal = std::max(std::max(rsweep, t_par), 1e-3);
+    const double w = std::min(1.0, std::max(0.0, (rsweep / t_par - 1.0) / 0.5));
+    r.fl = 1.0 - 0.4 * w; r.fb = 1.0 - 0.25 * w;
+    auto need = [](double cost, double t, uint32_t most) { return (uint32_t)std::min<double>(most, std::max(1.0, std::ceil(cost / t))); };
+    const uint32_t band_most = (nbands + PGM_WAVES - 1) / PGM_WAVES;
+    uint32_t lean = nlean ? need(lean_cost, r.fl * r.t_goal, nlean) : 0u, band = nbands ? need(band_cost, r.fb * r.t_goal, band_most) : 0u;
+    uint32_t rest = nrest ? need(rest_cost, r.t_goal, nrest) : 0u;
+    if (lean + band + rest > cap) {   // cut back in proportion to the work, at least one CU each (cap >= queues unless the device has fewer CUs than queues)
+        const double scale = (double)cap / (double)(lean + band + rest);
+        auto cut = [&](uint32_t v) { return v ? std::max(1u, (uint32_t)std::floor(v * scale)) : 0u; };
+        lean = cut(lean); band = cut(band); rest = cut(rest);
+        while (lean + band + rest > cap) {   // (rounding up to one CU each)
+            uint32_t *big = &rest; if (band > *big) big = &band; if (lean > *big) big = &lean;
+            if (*big <= 1u) break;
+            --*big;
+        }
+    }
+    r.rest_need = rest;
+    const uint32_t left = cap > lean + band + rest ? cap - lean - band - rest : 0u;
+    if (nrest) rest = std::min(nrest, rest + left);          // the main launch takes what is left ...
+    else if (nbands) band = std::min(band_most, band + left);   // ... or the band queue, or the lean queue
+    else if (nlean) lean = std::min(nlean, lean + left);
+    r.lean = lean; r.band = band; r.rest = rest;
+    return r;
+}
+
 #define PGM_STATUS_PENDING 0x7ffffff0   /* status word of a job's result record in the pinned block until its traceback worker has written it */
 static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     hipStream_t s = ctx->stream;
@@ -605,8 +655,10 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (fork && (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(ctx->stream3, b->ev_fork, 0)) != hipSuccess) return e;
     const uint32_t nrest = b->nitems - b->ncrit;
-    if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET);
+    if (critk && b->crit_c3) hipLaunchKernelGGL(pgm_crit_kernel, dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET);
+    else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET);
     if (nrest == 0) {}   // (no job for this launch)
+    else if (b->rest_c3) hipLaunchKernelGGL(pgm_crit_kernel, dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u);
     else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
     else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
     else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
@@ -657,6 +709,14 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
 }  // namespace
 
 extern "C" {
+
+int pgm_test_cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost, uint32_t nrest,
+                       uint32_t ncrit, double longest_chain, uint32_t *out4) {
+    if (!out4) return fail(PGM_ERR_INVALID, "null argument");
+    const CuShares r = cu_shares(cus, lean_cost, nlean, band_cost, nbands, rest_cost, nrest, ncrit, longest_chain);
+    out4[0] = r.lean; out4[1] = r.band; out4[2] = r.crit; out4[3] = r.rest;
+    return PGM_OK;
+}
 
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_batch **out) {
@@ -848,6 +908,13 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 J.long2 = (J.mode2 && o.s2.remote) ? 1u : 0u;
                 J.rh_off = J.slot_bytes;
                 if (J.long1 | J.long2) J.slot_bytes += 3u * 32u * 64u * 4u;   // W of the last 32 columns of every remote row's walk (one ring per row helper)
+                // MODE 2 jobs whose every predecessor is near or in the LDS history (no long / remote entries, no overflow columns, no
+                // generic nodes) are swept by pgm_crit_kernel: the chain terms on one wavefront, everything else on fifteen others
+                J.c3_off = J.slot_bytes;
+                J.crit3 = (J.mode2 && !J.long1 && !J.long2 && J.nov2 == 0 && o.s1.ngeneric + o.s2.ngeneric == 0 &&
+                           J.slot_bytes + (uint32_t)PGM_C3_BYTES <= (uint32_t)PGM_POOL && !tools_env("PGM_NO_CRIT3") && !tools_env("PGM_FILL_TRACE") &&
+                           !tools_env("PGM_TEST_NOSTORE") && !tools_env("PGM_FILL_DBG")) ? 1u : 0u;   // (the timeline and strip-down switches of the tools build belong to pgm_fill_kernel)
+                if (J.crit3) J.slot_bytes += (uint32_t)PGM_C3_BYTES;
                 J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.nslots = J.mode2 ? 1u : std::max(1u, std::min((uint32_t)PGM_WAVES, (uint32_t)PGM_POOL / J.slot_bytes));
                 if (J.lean) J.nslots = PGM_WAVES;
@@ -971,6 +1038,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = tools_env(k); return v ? atof(v) : d; };   // tools build only
         const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
+        const double tau_3 = envd("PGM_SIM_TAU_3", 0.42);   // a band of a crit3 job (pgm_crit_kernel)
         const double tau_l = envd("PGM_SIM_TAU_L", 0.27);   // lean sweep: us per step of R rows per lane
         // The jobs without helper wavefronts go to pgm_band_kernel, band by band (not with the timeline of the tools build, whose
         // slots are the fill kernel's items, and not a job whose sweep would not fit an eighth of the LDS)
@@ -980,7 +1048,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         for (uint32_t q = 0; q < njobs; ++q) {
             const uint32_t i = b->order[q];   // (largest first: the order of the lean queue)
             const PgmJob &J = b->jobs[i];
-            const double tau = J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c);     // us per step
+            const double tau = J.crit3 ? tau_3 : (J.mode2 ? tau_2 : (J.has_extras ? tau_x : tau_c));     // us per step
             const double tb = (J.has_extras ? 0.3 : 0.2) * (double)(J.n1 + J.n2);   // the traceback follows the last band (us)
             if (J.lean) {   // pgm_lean_kernel's queue: a worker's wavefronts cycle over the job's bands (72 steps behind each other), then the walk
                 const double rounds = std::ceil((double)J.nb / PGM_WAVES), first = std::min<double>(J.nb, PGM_WAVES);
@@ -1005,29 +1073,35 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
             total += per_job[i].size();
             total_b += per_job_b[i].size();
         }
-        // The CUs are split between the kernels (one worker per CU in each).  All three are waited for before the tracebacks start,
-        // so the time to beat is the longer of the longest chain of sweeps (rsweep) and the whole queue over all CUs: the lean
-        // queue gets the fewest CUs with which it is done within 0.6 of that, the band queue (eight bands at a time per CU) the
-        // fewest with which its simulated schedule ends within 0.75 of it (both measured on the headline batch, tools/ab_lib.sh:
-        // the sooner their traffic is out of the way the faster the longest chain runs, until the main launch starves), the fill kernel — one band of a MODE 2 job per CU, the
-        // chains that bound the batch — the rest.
-        double band_cost = 0.0;
+        // The CUs are split between the kernels (one worker per CU in each), see cu_shares(): the jobs with the longest chains of
+        // sweeps (within 15 % of the longest: the root of a guide tree, as a rule) get a launch of the fill kernel of their own, one CU
+        // per band — their tracebacks are the last thing a batch waits for, and this way the other jobs' tracebacks are out of the
+        // way before they start (each launch is followed by its own instance of pgm_tb_kernel); only if other jobs stay behind for
+        // the main launch.  The rest of the CUs is dealt to the lean queue, the band queue and the main launch by their costs.
+        double band_cost = 0.0, crit_cost = 0.0;
         for (uint32_t i = 0; i < njobs; ++i) { for (const Item &it : per_job[i]) other_cost += it.dur; for (const Item &it : per_job_b[i]) band_cost += it.dur / PGM_WAVES; }
-        const double t_goal = std::max(rsweep, (lean_cost + other_cost + band_cost) / std::max(1u, capacity));
-        uint32_t lean_cus = 0, band_cus = 0;
-        if (!lean_list.empty()) {
-            lean_cus = capacity;
-            if (total + total_b != 0) {
-                const uint32_t lo = std::min(4u, capacity - 1u);
-                for (lean_cus = lo; lean_cus + 4u < capacity; ++lean_cus)
-                    if (lean_cost / lean_cus <= 0.6 * std::max(t_goal, (other_cost + band_cost) / (double)(capacity - lean_cus))) break;
-            }
-            if (const char *v = tools_env("PGM_LEAN_CUS")) lean_cus = std::max(1u, std::min(capacity - (total + total_b != 0 ? 1u : 0u), (uint32_t)atoi(v)));
-            lean_cus = std::min<uint32_t>(lean_cus, (uint32_t)lean_list.size());
+        size_t total_c = 0;
+        if (use_bands && total != 0) {
+            uint32_t ncj = 0, nrestj = 0;
+            for (uint32_t i = 0; i < njobs; ++i) if (!per_job[i].empty()) { if (chain_of[i] >= 0.85 * rsweep) ++ncj; else ++nrestj; }
+            if (ncj != 0 && nrestj != 0)
+                for (uint32_t i = 0; i < njobs; ++i)
+                    if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) { total_c += per_job[i].size(); for (const Item &it : per_job[i]) crit_cost += it.dur; }
         }
+        CuShares sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)total_b, other_cost - crit_cost, (uint32_t)(total - total_c), (uint32_t)total_c, rsweep);
+        if (total_c != 0 && sh.crit == 0) {   // no CU to spare for a launch of their own: the longest chains stay in the main launch
+            total_c = 0; crit_cost = 0.0;
+            sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)total_b, other_cost, (uint32_t)total, 0u, rsweep);
+        }
+        if (total_c != 0)
+            for (uint32_t i = 0; i < njobs; ++i)
+                if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) per_job_c[i].swap(per_job[i]);
+        total -= total_c;
+        const double t_goal = sh.t_goal;
+        uint32_t lean_cus = sh.lean, band_cus = sh.band, crit_cus = sh.crit;
+        if (const char *v = tools_env("PGM_LEAN_CUS")) if (lean_cus) lean_cus = std::max(1u, std::min(std::min(capacity - 1u, (uint32_t)lean_list.size()), (uint32_t)atoi(v)));
         b->nlean = (uint32_t)lean_list.size();
         b->nlean_workers = lean_cus;
-        if (total + total_b != 0) capacity = std::max(1u, capacity - lean_cus);
         // event simulation: free workers (min-heap of times), ready items (max-heap of remaining paths), pending successors
         auto simulate = [&](std::vector<std::vector<Item>> &pj, size_t count, uint32_t workers, std::vector<PgmItem> &out) -> double {
             out.clear();
@@ -1063,39 +1137,22 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         };
         double band_end = 0.0;
         if (total_b != 0) {
-            const uint32_t most = total != 0 ? capacity - 1u : capacity;
-            band_cus = std::max(1u, std::min(most, (uint32_t)(band_cost / (0.75 * t_goal)) + 1u));
+            // (a simulation of a 1000-band list is 0.1 ms: the share grows by how far the simulated schedule overshoots, three times at
+            // most, and only into CUs the main launch does not need for its own share)
+            const uint32_t most = std::max(band_cus, band_cus + (sh.rest > sh.rest_need ? sh.rest - sh.rest_need : 0u));
             if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
             else if (total != 0) {
-                // (a simulation of a 1000-band list is 0.1 ms: the share is scaled by how far the schedule overshoots, three times at most)
                 for (int it = 0; it < 3 && band_cus < most; ++it) {
                     band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
-                    if (band_end <= 0.75 * t_goal) break;
-                    band_cus = std::min(most, std::max(band_cus + 1u, (uint32_t)std::ceil(band_cus * std::min(2.0, band_end / (0.75 * t_goal)))));
+                    if (band_end <= sh.fb * t_goal) break;
+                    band_cus = std::min(most, std::max(band_cus + 1u, (uint32_t)std::ceil(band_cus * std::min(2.0, band_end / (sh.fb * t_goal)))));
                 }
-            } else band_cus = most;
+            }
             band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
             band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
-            capacity = std::max(1u, capacity - band_cus);
         }
         b->nband_workers = band_cus;
-        // The jobs whose chains of sweeps are the longest of the batch (within 15 % of the longest: the root of a guide tree, as a
-        // rule) get a launch of the fill kernel of their own, on one CU per band: their tracebacks are the last thing a batch
-        // waits for, and this way the other jobs' tracebacks are out of the way before they start (each launch is followed by
-        // its own instance of pgm_tb_kernel).  Only if other jobs stay behind for the main launch.
-        size_t total_c = 0;
-        uint32_t crit_cus = 0;
-        if (use_bands && total != 0) {
-            uint32_t ncj = 0, nrestj = 0;
-            for (uint32_t i = 0; i < njobs; ++i) if (!per_job[i].empty()) { if (chain_of[i] >= 0.85 * rsweep) ++ncj; else ++nrestj; }
-            if (ncj != 0 && nrestj != 0) {
-                for (uint32_t i = 0; i < njobs; ++i)
-                    if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) { total_c += per_job[i].size(); per_job_c[i].swap(per_job[i]); }
-                crit_cus = (uint32_t)std::min<size_t>(total_c, capacity / 2u);
-                total -= total_c;
-                capacity -= crit_cus;
-            }
-        }
+        capacity = std::max(1u, capacity > lean_cus + band_cus + crit_cus ? capacity - lean_cus - band_cus - crit_cus : 1u);   // the main launch's CUs
         b->ncrit_workers = crit_cus;
         std::vector<PgmItem> items_rest;
         const double crit_end = total_c ? simulate(per_job_c, total_c, crit_cus, items) : 0.0;
@@ -1112,6 +1169,9 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     const double tc4 = now_ms();
     b->nitems = (uint32_t)items.size();
     b->nworkers = std::max(1u, std::min(capacity, b->nitems - b->ncrit));
+    b->crit_c3 = b->ncrit != 0; b->rest_c3 = b->nitems > b->ncrit;
+    for (size_t k = 0; k < items.size(); ++k)
+        if (!b->jobs[items[k].job].crit3) { if (k < b->ncrit) b->crit_c3 = false; else b->rest_c3 = false; }
     if (lean_list.empty()) lean_list.push_back(0u);
     if (tools_env("PGM_FILL_TRACE") && njobs &&   // (tools build) 6 words per item + 16 per item for the helper wavefronts, then 6 words per lean job
         hipMalloc((void **)&b->d_trace, 176 * items.size() + 48 * (size_t)njobs) != hipSuccess) {

@@ -102,6 +102,8 @@ struct PgmJob {
                            // cell and score storage are laid out per (band, step, r, lane), see `cells` / `S` below
     uint32_t lean;         // chain-only job (has_extras == 0): swept by pgm_sweep_chain — all bands of the job by ONE worker whose
                            // wavefronts hand the band's last row over through LDS rings (no hand-off through memory)
+    uint32_t crit3;        // mode2 job swept by pgm_crit_kernel (no long / remote entries, overflow columns or generic nodes): sixteen wavefronts per band
+    uint32_t c3_off;       // ... offset of its extra LDS (PGM_C3_*) inside the worker's slot
     uint32_t long1, long2; // mode2 only: graph 1 has REMOTE row entries / graph 2 has LONG column entries (served from the cell
                            // storage by the far helpers: farther than PGM_DCAP, or reaching above the band's virtual lanes)
     pgm_scores sc;
