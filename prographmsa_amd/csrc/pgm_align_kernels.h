@@ -2516,7 +2516,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
                                     //  the far helpers have three steps of lead, the wavefront of the step t - 3 term has none to give away)
                 const unsigned long long w0 = hst ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (seen < need) { if (GROUP == 0) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }
+                if (seen < need) { if (GROUP == 0 || tstr == 2u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4); }   // (pgm_crit_kernel's steps are short: a finer poll)
                 if (hst) hwait += __builtin_amdgcn_s_memrealtime() - w0;
             }
             asm volatile("" ::: "memory");

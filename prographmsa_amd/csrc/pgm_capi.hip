@@ -177,6 +177,7 @@ struct pgm_align_batch {
     int2 *d_tblist = nullptr;         // those jobs, largest first: (job, its last item of the work list)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // stream -> stream2 after the emission kernel, stream2 -> stream after the lean kernel
     unsigned long long *d_trace = nullptr;   // PGM_FILL_TRACE=file: per-item timeline, written by fetch (tools only)
+    unsigned long long *d_c3dbg = nullptr;   // PGM_C3_DBG (tools build): wait statistics of pgm_crit_kernel, 64 words per item, printed by fetch
     uint32_t test_spin_limit = 0, test_stall_job = 0xFFFFFFFFu, test_stall_band = 0;   // pgm_align_batch_test_stall
     double acc_ms[3] = {0, 0, 0};     // device time of prep / emission / fill (+ lean kernel + tracebacks) summed over the launches fetched since the last reset
     uint32_t acc_n = 0;
@@ -290,6 +291,7 @@ struct SideOff {
     uint32_t remote;              // MODE 2: entries served from the cell storage by the far helpers
     uint32_t nov;                 // MODE 2, columns: records of the overflow table in use
     uint32_t ngeneric;            // nodes served by the generic path
+    uint32_t nkill;               // interior nodes without predecessors
     // host only: far candidates (every finite edge outside the near slots) of node v: [cp[v], cp[v+1])
     std::vector<uint32_t> cp, cd;
     std::vector<float> cv;
@@ -303,7 +305,7 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
     std::vector<uint32_t> xc, pc, pu;
     std::vector<PgmNode2> ni(n);
-    o.nodes_with_extras = 0; o.has_long = 0; o.maxd_cap = 1; o.maxd_kf8 = 1;
+    o.nodes_with_extras = 0; o.has_long = 0; o.maxd_cap = 1; o.maxd_kf8 = 1; o.nkill = 0;
     o.cp.assign(n + 1, 0); o.cd.clear(); o.cv.clear();
     for (uint32_t v = 0; v < n; ++v) {
         PgmNode2 &I = ni[v];
@@ -352,7 +354,7 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
             for (uint32_t k = o.cp[v]; k < o.cp[v + 1] && small; ++k) { if (o.cd[k] > (uint32_t)PGM_DCAP) small = false; else dm = std::max(dm, o.cd[k]); }
             if (small) o.maxd_kf8 = std::max(o.maxd_kf8, dm);
         }
-        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) I.flags |= PGM_NF_KILL;  // interior node without predecessors
+        if (v > 0 && v + 1 < n && pp[v + 1] == pp[v]) { I.flags |= PGM_NF_KILL; ++o.nkill; }  // interior node without predecessors
         o.nodes_with_extras += (xp[v + 1] > xp[v]);
     }
     // at least one element each so that pointers are valid
@@ -655,10 +657,19 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (fork && (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(ctx->stream3, b->ev_fork, 0)) != hipSuccess) return e;
     const uint32_t nrest = b->nitems - b->ncrit;
-    if (critk && b->crit_c3) hipLaunchKernelGGL(pgm_crit_kernel, dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET);
+#ifdef PGM_TOOLS
+    if (tools_env("PGM_C3_DBG") && !b->d_c3dbg && b->nitems && hipMalloc((void **)&b->d_c3dbg, 512 * (size_t)b->nitems) != hipSuccess) b->d_c3dbg = nullptr;
+    if (b->d_c3dbg) (void)hipMemsetAsync(b->d_c3dbg, 0, 512 * (size_t)b->nitems, s);
+    if (critk && b->crit_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, b->d_c3dbg);
+    else
+#endif
+    if (critk && b->crit_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, (unsigned long long *)nullptr);
     else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET);
     if (nrest == 0) {}   // (no job for this launch)
-    else if (b->rest_c3) hipLaunchKernelGGL(pgm_crit_kernel, dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u);
+#ifdef PGM_TOOLS
+    else if (b->rest_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, b->d_c3dbg + 64 * (size_t)b->ncrit);
+#endif
+    else if (b->rest_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, (unsigned long long *)nullptr);
     else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
     else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
     else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
@@ -911,9 +922,15 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 // MODE 2 jobs whose every predecessor is near or in the LDS history (no long / remote entries, no overflow columns, no
                 // generic nodes) are swept by pgm_crit_kernel: the chain terms on one wavefront, everything else on fifteen others
                 J.c3_off = J.slot_bytes;
-                J.crit3 = (J.mode2 && !J.long1 && !J.long2 && J.nov2 == 0 && o.s1.ngeneric + o.s2.ngeneric == 0 &&
+                // (and no interior node without predecessors: the chain wavefront carries no code for them)
+                J.crit3 = (J.mode2 && !J.long1 && !J.long2 && J.nov2 == 0 && o.s1.ngeneric + o.s2.ngeneric == 0 && o.s1.nkill + o.s2.nkill == 0 &&
                            J.slot_bytes + (uint32_t)PGM_C3_BYTES <= (uint32_t)PGM_POOL && !tools_env("PGM_NO_CRIT3") && !tools_env("PGM_FILL_TRACE") &&
                            !tools_env("PGM_TEST_NOSTORE") && !tools_env("PGM_FILL_DBG")) ? 1u : 0u;   // (the timeline and strip-down switches of the tools build belong to pgm_fill_kernel)
+                if (J.crit3 && J.hDX < 8u) {   // (the chain wavefront addresses a block of eight steps from one base: no ring wraps inside a block)
+                    J.slot_bytes += (8u - J.hDX) * 256u; J.aux_off += (8u - J.hDX) * 256u; J.ov_off += (8u - J.hDX) * 256u; J.rh_off += (8u - J.hDX) * 256u; J.c3_off += (8u - J.hDX) * 256u;
+                    J.hDX = 8u;
+                    if (J.slot_bytes + (uint32_t)PGM_C3_BYTES > (uint32_t)PGM_POOL) J.crit3 = 0u;   // (cannot happen: a deep W / Y history comes with a deep X history)
+                }
                 if (J.crit3) J.slot_bytes += (uint32_t)PGM_C3_BYTES;
                 J.far_slack = std::max(1u, std::min(4u, std::min(o.s1.far_dmin, o.s2.far_dmin)));
                 J.nslots = J.mode2 ? 1u : std::max(1u, std::min((uint32_t)PGM_WAVES, (uint32_t)PGM_POOL / J.slot_bytes));
@@ -1331,6 +1348,27 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
         }
     }
 #endif
+#ifdef PGM_TOOLS
+    if (b->d_c3dbg && tools_env("PGM_C3_DBG")) {   // who waits for whom in pgm_crit_kernel: per job, means over its bands (ticks of 10 ns -> us)
+        std::vector<unsigned long long> dg(64 * (size_t)b->nitems);
+        std::vector<PgmItem> its(b->nitems);
+        (void)hipMemcpy(dg.data(), b->d_c3dbg, 512 * (size_t)b->nitems, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(its.data(), b->d_items, sizeof(PgmItem) * b->nitems, hipMemcpyDeviceToHost);
+        const uint32_t want = (uint32_t)atoi(tools_env("PGM_C3_DBG"));   // job index + 1 (0: every job)
+        for (uint32_t j = 0; j < b->njobs; ++j) {
+            if (!b->jobs[j].crit3 || (want && want != j + 1)) continue;
+            double acc[64] = {0}; uint32_t n = 0;
+            for (uint32_t k = 0; k < b->nitems; ++k) if (its[k].job == j) { for (int w = 0; w < 64; ++w) acc[w] += (double)dg[64 * (size_t)k + w]; ++n; }
+            if (!n) continue;
+            for (double &v : acc) v /= n * 100.0;
+            fprintf(stderr, "c3dbg job %u (%u x %u, %u bands, %u steps): chain %.0f us, of it waiting for fold %.0f, for the band above %.0f (%.0f waits per band) | fold 0: %.0f us, waiting for the record %.0f, for helpers %.0f (%.0f late) | fold 1: %.0f / %.0f / %.0f (%.0f) | near: %.0f us waiting %.0f; %.0f / %.0f\n",
+                    j, b->jobs[j].n1, b->jobs[j].n2, b->jobs[j].nb, b->jobs[j].tsteps, acc[0], acc[1], acc[2], acc[3] * 100.0, acc[4], acc[5], acc[6], acc[7] * 100.0, acc[8], acc[9], acc[10], acc[11] * 100.0, acc[12], acc[13], acc[16], acc[17]);
+            fprintf(stderr, "   helpers (poll us / all us): columns");
+            for (int k = 0; k < 10; ++k) { const int w = k < 8 ? 20 + k : 28 + k; fprintf(stderr, "%s %.0f/%.0f", k == 4 ? " | rows" : "", acc[w], acc[w + 8]); }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (aborted) return fail(PGM_ERR_DEVICE, "fill kernel: a band hand-off timed out");
     if (b->d_trace) {
         // timeline dump for tools/probe_trace.py: nitems x {worker, start, band end, traceback end} + the item list
@@ -1388,6 +1426,7 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     cache_give(ctx, pgm_ctx::C_HOST, b->h_out, b->cap[pgm_ctx::C_HOST]);
     cache_give(ctx, pgm_ctx::C_HIN, b->h_in, b->cap[pgm_ctx::C_HIN]);
     if (b->d_trace) (void)hipFree(b->d_trace);
+    if (b->d_c3dbg) (void)hipFree(b->d_c3dbg);
     delete b;
 }
 
