@@ -153,12 +153,13 @@ int pgm_align_batch_job_times(pgm_ctx *ctx, pgm_align_batch *b, uint64_t *ticks)
  * and a wavefront that waits for another gives up after `spin_limit` polls (0: the default); the band below then times out,
  * raises the batch's abort flag and every unfinished job reports PGM_ERR_DEVICE.  job = 0xFFFFFFFF switches it off. */
 int pgm_align_batch_test_stall(pgm_align_batch *b, uint32_t job, uint32_t band, uint32_t spin_limit);
-/* Test hook (host arithmetic only, no device call): how `cus` compute units are dealt to the four sweep launches of a batch —
- * out4 = {lean queue, band queue, launch of the longest chains, main launch} — given each queue's work in microseconds of one
- * worker, its number of units (lean jobs, bands, items of the main launch, items of the longest chains) and the longest chain
- * of sweeps in microseconds.  Every queue with work gets at least one CU and the shares never exceed `cus`. */
+/* Test hook (host arithmetic only, no device call): how `cus` compute units are dealt to the launches of a batch's fill stage —
+ * out5 = {lean queue, band queue, launch of the longest chains, main launch, traceback kernel beside the sweeps} — given each
+ * queue's work in microseconds of one worker, its number of units (lean jobs, bands, items of the main launch, items of the
+ * longest chains, tracebacks; ntb = 0: the tracebacks follow their launches) and the longest chain of sweeps in microseconds.
+ * Every queue with work gets at least one CU and the shares never exceed `cus`. */
 int pgm_test_cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost,
-                       uint32_t nrest, uint32_t ncrit, double longest_chain, uint32_t *out4);
+                       uint32_t nrest, uint32_t ncrit, double longest_chain, double tb_cost, uint32_t ntb, uint32_t *out5);
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
  * column-major, element (y,x) at y + x*n1).  Only rows < n1-1 and columns < n2-1 are
  * defined (the END row/column are never written by the reference's fill either).

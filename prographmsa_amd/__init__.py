@@ -92,7 +92,7 @@ def _load():
         "pgm_align_batch_destroy": (None, [vp, vp]),
         "pgm_align_batch_cells": (C.c_uint64, [vp]),
         "pgm_align_batch_test_stall": (C.c_int, [vp, u32, u32, u32]),
-        "pgm_test_cu_shares": (C.c_int, [u32, C.c_double, u32, C.c_double, u32, C.c_double, u32, u32, C.c_double, C.POINTER(C.c_uint32)]),
+        "pgm_test_cu_shares": (C.c_int, [u32, C.c_double, u32, C.c_double, u32, C.c_double, u32, u32, C.c_double, C.c_double, u32, C.POINTER(C.c_uint32)]),
         "pgm_align_batch_stage_times": (C.c_int, [vp, C.c_int] + [C.POINTER(C.c_float)] * 3 + [C.POINTER(u32)]),
         "pgm_align_batch_job_times": (C.c_int, [vp, vp, C.POINTER(C.c_uint64)]),
         "pgm_align_batch_time": (C.c_int, [vp, vp, C.c_int] + [C.POINTER(C.c_float)] * 4),

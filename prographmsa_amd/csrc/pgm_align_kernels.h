@@ -1400,6 +1400,15 @@ __device__ static void pgm_prelink_tile(const PgmJob &J, PgmLkLds &G, const uint
 }
 
 #define PGM_SPIN_LIMIT (1u << 24)
+#define PGM_IDLE_LIMIT_TICKS 400000000ull   /* 4 s of the 100 MHz real-time counter: a worker that has seen nothing happen for that long raises the abort flag */
+
+// A job's last band is complete (and every store of it waited for): append the job to the ready queue of the traceback kernel that
+// runs beside the sweeps (tbq_off == 0: the tracebacks follow on the stream instead).
+__device__ __forceinline__ void pgm_tbq_push(int *sync, const uint32_t tbq_off, const uint32_t job) {
+    if (tbq_off == 0u) return;
+    const int k = __hip_atomic_fetch_add(sync + PGM_SY_TBQ_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sync + tbq_off + k, (int)job + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Fill kernel (GraphAlign.h:212-260 incl. the border initialisation as row/column 0).
@@ -2712,7 +2721,7 @@ __device__ __forceinline__ void pgm_terms_helper(const PgmJob &J, const uint32_t
 template <bool NOTRACEBACK, bool DBG>
 __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                       int *__restrict__ sync, unsigned long long *__restrict__ trace,
-                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_, uint32_t ticket_off) {
+                                                      uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t dbg_flags_, uint32_t ticket_off, uint32_t tbq_off) {
     const uint32_t dbg_flags = DBG ? dbg_flags_ : 0u;
     if (!DBG) trace = nullptr;
     int *abort_flag = sync;        // [0] abort flag, [1] ticket counter of the band list, [2] lean list; the traceback kernel's words from [32] on (PGM_SY_*)
@@ -2783,7 +2792,7 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
             if (threadIdx.x == 0) J.times[0] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            } else if (threadIdx.x == 0) pgm_tbq_push(sync, tbq_off, item.job);
         }
     }
 }
@@ -2797,18 +2806,25 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_fill_kernel(const PgmJo
 // (ordered by the host like the items: longest remaining path first, a job's bands ascending) and sweeps it in its own
 // eighth of the CU's LDS; nothing in a MODE 0 / 1 sweep involves another wavefront.  Runs beside pgm_fill_kernel (which keeps
 // the MODE 2 jobs) and pgm_lean_kernel on a stream of its own, on its share of the CUs; pgm_tb_kernel follows all three.
-__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_band_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ bands, uint32_t nbands,
-                                                                  int *__restrict__ sync, uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band) {
+// The list has two parts: [0, nnarrow) bands whose sweep fits an eighth of the CU's LDS — workers 0 .. nworkers_narrow - 1, eight
+// sweeping wavefronts each — and [nnarrow, nbands) WIDE bands that need up to a quarter (a 32-step history: the middle levels of a
+// guide tree) — the remaining workers, PGM_WIDE_WAVES sweeping wavefronts each (the others leave).
+__global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_band_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ bands, uint32_t nnarrow, uint32_t nbands,
+                                                                  uint32_t nworkers_narrow, int *__restrict__ sync, uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t tbq_off) {
     __shared__ __attribute__((aligned(16))) uint8_t pool[PGM_POOL];
     int *abort_flag = sync;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    uint8_t *slot = pool + (size_t)role * (PGM_POOL / PGM_WAVES / 16 * 16);
+    const bool wide = blockIdx.x >= nworkers_narrow;
+    if (wide && role >= PGM_WIDE_WAVES) return;
+    uint8_t *slot = pool + (size_t)role * (wide ? (PGM_POOL / PGM_WIDE_WAVES / 16 * 16) : (PGM_POOL / PGM_WAVES / 16 * 16));
+    const uint32_t qbase = wide ? nnarrow : 0u, qend = wide ? nbands : nnarrow;
+    int *ticket = sync + (wide ? PGM_SY_WIDE_TICKET : PGM_SY_BAND_TICKET);
     bool aborted = false;
     for (;;) {
         // every lane takes part in the dequeue (lane 0 adds 1, the others 0), see pgm_nw_kernel
-        uint32_t q = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_BAND_TICKET, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-        if (q >= nbands || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        uint32_t q = (uint32_t)__hip_atomic_fetch_add(ticket, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = qbase + (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        if (q >= qend || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         const PgmItem item = bands[q];
         {   // s_setprio takes an immediate
             const uint32_t pr = __builtin_amdgcn_readfirstlane(item.prio);
@@ -2822,42 +2838,71 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_band_kernel(const PgmJo
         if (b + 1u == J.nb && lane == 0) J.times[0] = __builtin_amdgcn_s_memrealtime();
         if (b + 1u == J.nb && lane == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // an aborted batch leaves its records here
             J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        } else if (b + 1u == J.nb && lane == 0) pgm_tbq_push(sync, tbq_off, item.job);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tracebacks of the jobs pgm_fill_kernel has swept, and the pre-linking that makes the long ones short.  The kernel follows the
-// fill kernel on its stream (every cell is final and visible); one worker of 512 threads per CU.  A worker takes jobs from the
-// list — largest first: its walk is the longest — until there is none left; from then on it pre-links grid tiles of the
-// corridors of the tracebacks still under way (pgm_prelink_tile), in the order their walkers will reach them, and leaves when
-// the last traceback has finished.  After the root of a guide tree, one job on one worker, everybody else pre-links: the
-// serial stage-link-walk of that traceback becomes one table load per grid row.
-// (Tried first: this kernel BESIDE the fill kernel on a third stream, fed through a queue by the workers that complete a job's
-// last band.  Its idle workers have to wait for CUs, and with its grid pending behind the fill kernel's for milliseconds the
-// sweeps stopped making progress in one launch of a few hundred — until this kernel's workers ran into their poll limit a
-// minute later.  Not understood, not shipped.)
+// Tracebacks of the jobs the sweep kernels (pgm_fill_kernel, pgm_crit_kernel, pgm_band_kernel) have swept, and the pre-linking that
+// makes the long ones short.  One worker of 512 threads per CU.  A worker takes jobs until there is none left; from then on (and
+// while the job it has claimed is still being swept) it pre-links grid tiles of the corridors of the tracebacks under way
+// (pgm_prelink_tile), in the order their walkers will reach them, and leaves when the last traceback has finished.
+//
+// Two ways of getting jobs:
+//   tbq_off == 0  the kernel FOLLOWS a sweep kernel on its stream (every cell final and visible): entry k of `list`, largest job first
+//   tbq_off != 0  the kernel runs BESIDE the sweep kernels from the start of the stage, on CUs of its own (round 4: with the sweeps
+//                 fast, a traceback that only starts when its whole launch is through was the longest tail of the stage): the worker
+//                 that completes a job's last band appends the job to the ready queue sync_[tbq_off ..] (pgm_tbq_push); a worker
+//                 here claims queue position k, waits for its entry (agent-scope acquire: the job's cells were written through by
+//                 wavefronts that waited for their stores before they published their progress) and walks that job.
+//   walk == 0     pre-link only: instances that follow a sweep kernel on its CUs and lend them to the tracebacks still under way.
+// All grids of a stage are resident together (their workers add up to the CUs of the device).  Round 3 ran this kernel beside the
+// sweeps with its grid WAITING for CUs and saw the sweeps stop for a minute in one launch of a few hundred: every sweep worker was
+// resident (counters), ticket 250 of 787 taken, bands with a finished predecessor not started, the traceback grid with zero CUs.
+// Nothing in the kernels waits for the traceback grid, so the waves were not waiting for each other: they were not running.  With
+// more runnable queues than the device can hold, the hardware scheduler time-slices the queues — it saves the resident waves of one
+// (they keep their place in the list but make no progress) to let the other in, which cannot make progress either while the first
+// still owns work it needs; every switch costs milliseconds, and a poll budget counted in polls, not in time, stretched the
+// round trips to a minute.  Hence the rule, enforced by the host (cu_shares): no grid of a stage ever waits for a CU.
 template <bool DBG>
 __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob *__restrict__ jobs, const int2 *__restrict__ list, uint32_t ntb, int *__restrict__ sync_,
-                                                                unsigned long long *__restrict__ trace, uint32_t spin_limit, uint32_t lq_off, uint32_t sybase) {
+                                                                unsigned long long *__restrict__ trace, uint32_t spin_limit, uint32_t lq_off, uint32_t sybase,
+                                                                uint32_t tbq_off, uint32_t walk) {
     if (!DBG) trace = nullptr;
     __shared__ __attribute__((aligned(16))) union { PgmTbLds t; PgmLkLds g; } L;
     __shared__ int cmd_lds, arg_lds;
     // (a batch has up to two instances of this kernel — behind pgm_band_kernel and behind pgm_fill_kernel — each with its own
     // list, counters (sybase) and announcements)
     int *abort_flag = sync_, *sync = sync_ + sybase, *lq = sync + PGM_SY_LQ_N, *lq_ids = sync_ + lq_off;
-    bool walking = true;   // there may be a job left in the list
+    bool walking = walk != 0u;   // there may be a job left to take
+    int claimed = -1;            // (thread 0, tbq_off != 0) position of the ready queue this worker has claimed and is waiting for
     uint32_t lk_backoff = 0u, lk_first = 0u;   // (thread 0: first announcement that may still have tiles)
-    for (uint32_t polls = 0; polls < (spin_limit ? spin_limit : PGM_SPIN_LIMIT); ++polls) {
+    // the worker gives up — and says so: abort flag — after spin_limit idle polls (the hand-off test's knob) or, by default, when
+    // nothing has happened for PGM_IDLE_LIMIT_TICKS of the real-time counter (not after a number of polls: a poll's length varies)
+    unsigned long long idle_since = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t polls = 0;; ++polls) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            int cmd = -2;   // -3: traceback of list entry arg; >= 0: pre-link tile cmd of job arg; -2: nothing right now; -1: leave
+            int cmd = -2;   // -3: traceback of job arg (list entry arg when following a kernel); >= 0: pre-link tile cmd of job arg; -2: nothing right now; -1: leave
             if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                 (uint32_t)__hip_atomic_load(sync + PGM_SY_TB_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntb) cmd = -1;
-            else if (walking) {
+            else if ((spin_limit && polls > spin_limit) || (!spin_limit && (polls & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - idle_since > PGM_IDLE_LIMIT_TICKS)) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cmd = -1;
+            } else if (walking && tbq_off == 0u) {
                 const uint32_t k = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_TBQ_N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k < ntb) { cmd = -3; arg_lds = (int)k; } else cmd = -5;
-            } else if ((polls & ((1u << lk_backoff) - 1u)) == 0u) {
+                if (k < ntb) { cmd = -3; arg_lds = list[k].x; } else cmd = -5;
+            } else if (walking) {
+                if (claimed < 0) {
+                    const uint32_t k = (uint32_t)__hip_atomic_fetch_add(sync + PGM_SY_TBQ_N, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k < ntb) claimed = (int)k; else cmd = -5;
+                }
+                if (claimed >= 0) {
+                    const int id = __hip_atomic_load(sync_ + tbq_off + claimed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (id != 0) { cmd = -3; arg_lds = id - 1; claimed = -1; }
+                }
+            }
+            if (cmd == -2 && (polls & ((1u << lk_backoff) - 1u)) == 0u) {
                 // pre-link: the first announcements first (the jobs are taken largest first, so these are the longest walks), at most
                 // eight with tiles left looked at per poll; the grid rows a walker has left are skipped in one step
                 const uint32_t na = (uint32_t)__hip_atomic_load(lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2885,15 +2930,23 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 1) pgm_tb_kernel(const PgmJob 
         const int cmd = cmd_lds;
         if (cmd == -1) break;
         if (cmd == -5) { walking = false; continue; }
-        if (cmd == -2) { lk_backoff = min(lk_backoff + 1u, 3u); __builtin_amdgcn_s_sleep(127); continue; }   // ~3 us; the announcements are looked at every 2, 4, 8 polls while they have nothing
+        if (cmd == -2) { lk_backoff = min(lk_backoff + 1u, 3u); if (walking) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127); continue; }   // ~1 / ~3 us; the announcements are looked at every 2, 4, 8 polls while they have nothing
         lk_backoff = 0u;
+        if (threadIdx.x == 0) idle_since = __builtin_amdgcn_s_memrealtime();
         if (cmd == -3) {
-            const int2 e = list[arg_lds];   // (job, its last item of the work list: the timeline's slot)
-            const int it = e.y;
-            pgm_traceback_job(jobs[e.x], L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr, lq, lq_ids, (uint32_t)e.x);
-            if (threadIdx.x == 0) jobs[e.x].times[1] = __builtin_amdgcn_s_memrealtime();
+            const int jid = arg_lds;
+            int it = 0;   // (the job's last item of the work list: the timeline's slot; tools build, following a kernel)
+            if (trace) for (uint32_t k = 0; k < ntb; ++k) if (list[k].x == jid) it = list[k].y;
+            if (tbq_off != 0u) {   // the job's cells come from other CUs of this very stage: nothing stale in this CU's cache
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            pgm_traceback_job(jobs[jid], L.t, (int)threadIdx.x, 64 * PGM_WAVES, trace ? trace + 6 * it + 4 : nullptr, lq, lq_ids, (uint32_t)jid);
+            if (threadIdx.x == 0) jobs[jid].times[1] = __builtin_amdgcn_s_memrealtime();
             if (trace && threadIdx.x == 0) trace[6 * it + 3] = __builtin_amdgcn_s_memrealtime();
         } else {
+            if (tbq_off != 0u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
             pgm_prelink_tile(jobs[arg_lds], L.g, (uint32_t)cmd, (int)threadIdx.x);
         }
     }

@@ -58,6 +58,7 @@ struct pgm_ctx {
     hipStream_t stream2 = nullptr;   // the lean kernel runs beside the fill kernel (pgm_lean_kernel)
     hipStream_t stream3 = nullptr;   // ... and so does the band kernel (pgm_band_kernel)
     hipStream_t stream4 = nullptr;   // ... and the fill kernel's launch for the longest chains
+    hipStream_t stream5 = nullptr;   // ... and the traceback kernel that runs beside them
     // The big buffers of a destroyed batch are kept for the next one (a progressive alignment issues one batch per tree
     // level: hipMalloc / hipFree of several GB per call would dominate the call).  Slot k holds at most one buffer.
     enum { C_IN, C_WORK, C_CELLS, C_OUT, C_S, C_HOST, C_HIN, C_SMALL, C_SLOTS };   // C_HOST, C_HIN: pinned host memory; C_SMALL: the batch's counters, job descriptors, work list
@@ -166,9 +167,12 @@ struct pgm_align_batch {
     uint32_t *d_lean = nullptr;       // the lean jobs (pgm_lean_kernel's work queue), largest first
     uint32_t nlean = 0, nlean_workers = 0;
     uint32_t nbands = 0, nband_workers = 0;   // pgm_band_kernel: bands of the MODE 0 / 1 jobs, one per wavefront; its workers (CUs)
+    uint32_t nbands_narrow = 0, nwide_workers = 0;   // ... the first nbands_narrow of the list: sweeps that fit an eighth of a CU's LDS; the rest: a quarter, swept by the last nwide_workers workers (four wavefronts each)
     PgmItem *d_bands = nullptr;
     unsigned long long *d_times = nullptr;   // per job {last band complete, traceback published}, then the launch's start (ticks of 10 ns)
     hipEvent_t ev_join_b = nullptr;
+    uint32_t ntb_beside_workers = 0, tbq_off = 0;   // pgm_tb_kernel beside the sweeps: its workers (0: the tracebacks follow their launches), its ready queue inside d_sync
+    hipEvent_t ev_join_t = nullptr;
     bool crit_c3 = false, rest_c3 = false;   // every item of the launch for the longest chains / of the main launch belongs to a crit3 job: pgm_crit_kernel sweeps that list
     uint32_t ncrit = 0, ncrit_workers = 0, ntb_c = 0;   // the first ncrit items of the work list: the jobs with the longest chains, swept by a launch of their own on their own CUs; their tracebacks
     hipEvent_t ev_join_c = nullptr;
@@ -218,6 +222,7 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream5, hipStreamNonBlocking));
     {   // (the launch of the longest chains on the highest stream priority the device offers)
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
@@ -258,6 +263,7 @@ void pgm_ctx_destroy(pgm_ctx *ctx) {
     for (int k = 0; k < 2; ++k) if (ctx->sc_ev[k]) (void)hipEventDestroy(ctx->sc_ev[k]);
     for (int k = 0; k < pgm_ctx::C_SLOTS; ++k)
         if (ctx->cache_ptr[k]) slot_free(k, ctx->cache_ptr[k]);
+    if (ctx->stream5) (void)hipStreamDestroy(ctx->stream5);
     if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -571,25 +577,29 @@ static hipError_t scratch_events(pgm_ctx *ctx) {
     return hipSuccess;
 }
 
-// How the CUs of the device are dealt to the four sweep launches of a batch (pure arithmetic; pgm_test_cu_shares exports it for
-// the CPU tests).  Every launch is a grid of persistent workers, one per CU, and all four are resident together (no grid ever
-// waits for a CU), so the shares add up to at most `cus` and every queue with work gets at least one CU.
+// How the CUs of the device are dealt to the launches of a batch's fill stage (pure arithmetic; pgm_test_cu_shares exports it for
+// the CPU tests).  Every launch is a grid of persistent workers, one per CU, and all of them are resident together (no grid ever
+// waits for a CU: pgm_tb_kernel's header says why), so the shares add up to at most `cus` and every queue with work gets at least one.
 //   crit   the launch of the longest chains: one CU per band, at most half of the device, and only if it leaves every other
 //          queue with work at least one CU (else 0: the caller leaves those jobs in the main launch)
 //   then the time to beat is t_goal = max(longest chain of sweeps, all other work / the other CUs).  A batch bound by that chain
 //   (chain >= 1.5 x the parallel time) wants the other launches' traffic out of the chain's way early: the lean queue gets the
 //   fewest CUs with which it ends within 0.6 t_goal, the band queue within 0.75 t_goal (measured on the headline batch, round 3);
 //   a batch bound by throughput wants every queue to end together: the factors go to 1 as the chain's lead shrinks to nothing.
-//   rest   the main launch: what is left, never less than its own work needs to end within t_goal — if the three shares do not fit,
-//          they are cut back in proportion to their work.
-struct CuShares { uint32_t lean, band, crit, rest, rest_need; double t_goal, fl, fb; };
-static CuShares cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost, uint32_t nrest, uint32_t ncrit, double rsweep) {
-    CuShares r = {0u, 0u, 0u, 0u, 0u, 0.0, 1.0, 1.0};
+//   tb     the traceback kernel that runs beside the sweeps (ntb = 0: the tracebacks follow their launches instead): a third of its
+//          work over t_goal — the jobs of a level end together, late in the stage, when the CUs of the sweep kernels join in (an
+//          instance of the kernel follows each of them); the workers here take the early finishers — at most a third of the CUs
+//   rest   the main launch: what is left, never less than its own work needs to end within t_goal — if the shares do not fit,
+//          they are cut back in proportion.
+struct CuShares { uint32_t lean, band, crit, rest, tb, rest_need; double t_goal, fl, fb; };
+static CuShares cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost, uint32_t nrest, uint32_t ncrit, double rsweep,
+                          double tb_cost = 0.0, uint32_t ntb = 0, double tb_frac = 0.35) {
+    CuShares r = {0u, 0u, 0u, 0u, 0u, 0u, 0.0, 1.0, 1.0};
     cus = std::max(1u, cus);
-    const uint32_t queues = (nlean != 0) + (nbands != 0) + (nrest != 0);
+    const uint32_t queues = (nlean != 0) + (nbands != 0) + (nrest != 0) + (ntb != 0);
     if (ncrit != 0 && cus > queues) r.crit = std::min(std::min(ncrit, cus / 2u), cus - queues);
     const uint32_t cap = std::max(1u, cus - r.crit);
-    const double sum = (nlean ? lean_cost : 0.0) + (nbands ? band_cost : 0.0) + (nrest ? rest_cost : 0.0);
+    const double sum = (nlean ? lean_cost : 0.0) + (nbands ? band_cost : 0.0) + (nrest ? rest_cost : 0.0) + (ntb ? tb_cost : 0.0);
     const double t_par = std::max(1e-3, sum / cap);
     r.t_goal = std::max(std::max(rsweep, t_par), 1e-3);
     const double w = std::min(1.0, std::max(0.0, (rsweep / t_par - 1.0) / 0.5));
@@ -598,22 +608,23 @@ static CuShares cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double
     const uint32_t band_most = (nbands + PGM_WAVES - 1) / PGM_WAVES;
     uint32_t lean = nlean ? need(lean_cost, r.fl * r.t_goal, nlean) : 0u, band = nbands ? need(band_cost, r.fb * r.t_goal, band_most) : 0u;
     uint32_t rest = nrest ? need(rest_cost, r.t_goal, nrest) : 0u;
-    if (lean + band + rest > cap) {   // cut back in proportion to the work, at least one CU each (cap >= queues unless the device has fewer CUs than queues)
-        const double scale = (double)cap / (double)(lean + band + rest);
+    uint32_t tb = ntb ? need(tb_frac * tb_cost, r.t_goal, std::max(1u, std::min(ntb, cap / 3u))) : 0u;
+    if (lean + band + rest + tb > cap) {   // cut back in proportion to the work, at least one CU each (cap >= queues unless the device has fewer CUs than queues)
+        const double scale = (double)cap / (double)(lean + band + rest + tb);
         auto cut = [&](uint32_t v) { return v ? std::max(1u, (uint32_t)std::floor(v * scale)) : 0u; };
-        lean = cut(lean); band = cut(band); rest = cut(rest);
-        while (lean + band + rest > cap) {   // (rounding up to one CU each)
-            uint32_t *big = &rest; if (band > *big) big = &band; if (lean > *big) big = &lean;
+        lean = cut(lean); band = cut(band); rest = cut(rest); tb = cut(tb);
+        while (lean + band + rest + tb > cap) {   // (rounding up to one CU each)
+            uint32_t *big = &rest; if (band > *big) big = &band; if (lean > *big) big = &lean; if (tb > *big) big = &tb;
             if (*big <= 1u) break;
             --*big;
         }
     }
     r.rest_need = rest;
-    const uint32_t left = cap > lean + band + rest ? cap - lean - band - rest : 0u;
+    const uint32_t left = cap > lean + band + rest + tb ? cap - lean - band - rest - tb : 0u;
     if (nrest) rest = std::min(nrest, rest + left);          // the main launch takes what is left ...
     else if (nbands) band = std::min(band_most, band + left);   // ... or the band queue, or the lean queue
     else if (nlean) lean = std::min(nlean, lean + left);
-    r.lean = lean; r.band = band; r.rest = rest;
+    r.lean = lean; r.band = band; r.rest = rest; r.tb = tb;
     return r;
 }
 
@@ -652,7 +663,16 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     const bool bandk = b->nbands != 0;
     const bool tbk = (b->nitems != 0 || bandk) && (b->ntb + b->ntb_c + b->ntb_b) != 0 && dbgv != 8 && !tools_env("PGM_NO_TBK");   // the traceback kernel behind the fill kernel (PGM_NO_TBK, tools build: the sweeps alone, every result stays pending)
     const bool critk = b->ncrit != 0;
-    if ((fork || bandk || critk) && (e = hipEventRecord(b->ev_fork, s)) != hipSuccess) return e;
+    const uint32_t ntb_all = b->ntb + b->ntb_c + b->ntb_b;
+    const bool beside = tbk && b->ntb_beside_workers != 0 && !b->d_trace;   // the tracebacks run beside the sweeps (else: behind their launches)
+    const uint32_t tbq = beside ? b->tbq_off : 0u;
+    if ((fork || bandk || critk || beside) && (e = hipEventRecord(b->ev_fork, s)) != hipSuccess) return e;
+    if (beside) {   // first of all, so that its workers are resident when the sweep grids fill the rest of the device
+        if ((e = hipStreamWaitEvent(ctx->stream5, b->ev_fork, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_beside_workers), dim3(64 * PGM_WAVES), 0, ctx->stream5, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(b->ev_join_t, ctx->stream5)) != hipSuccess) return e;
+    }
     if (critk && (e = hipStreamWaitEvent(ctx->stream4, b->ev_fork, 0)) != hipSuccess) return e;
     if (fork && (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(ctx->stream3, b->ev_fork, 0)) != hipSuccess) return e;
@@ -660,19 +680,19 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
 #ifdef PGM_TOOLS
     if (tools_env("PGM_C3_DBG") && !b->d_c3dbg && b->nitems && hipMalloc((void **)&b->d_c3dbg, 512 * (size_t)b->nitems) != hipSuccess) b->d_c3dbg = nullptr;
     if (b->d_c3dbg) (void)hipMemsetAsync(b->d_c3dbg, 0, 512 * (size_t)b->nitems, s);
-    if (critk && b->crit_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, b->d_c3dbg);
+    if (critk && b->crit_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, b->d_c3dbg, tbq);
     else
 #endif
-    if (critk && b->crit_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, (unsigned long long *)nullptr);
-    else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET);
+    if (critk && b->crit_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, (unsigned long long *)nullptr, tbq);
+    else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET, tbq);
     if (nrest == 0) {}   // (no job for this launch)
 #ifdef PGM_TOOLS
-    else if (b->rest_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, b->d_c3dbg + 64 * (size_t)b->ncrit);
+    else if (b->rest_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, b->d_c3dbg + 64 * (size_t)b->ncrit, tbq);
 #endif
-    else if (b->rest_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, (unsigned long long *)nullptr);
-    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
-    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u);
+    else if (b->rest_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, (unsigned long long *)nullptr, tbq);
+    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
+    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (fork) {
         // the lean jobs' kernel, launched after the fill kernel (whose grid leaves nlean_workers CUs free)
@@ -689,27 +709,30 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (bandk) {
         // the bands of the MODE 0 / 1 jobs, one per wavefront, on their share of the CUs; their tracebacks follow on the same
         // stream and the same CUs (the band queue is done well before the chains of the fill kernel are)
-        hipLaunchKernelGGL(pgm_band_kernel, dim3(b->nband_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_bands, b->nbands, b->d_sync, spin_limit, stall_job, stall_band);
+        hipLaunchKernelGGL(pgm_band_kernel, dim3(b->nband_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_bands, b->nbands_narrow, b->nbands, b->nband_workers - b->nwide_workers, b->d_sync, spin_limit, stall_job, stall_band, tbq);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (tbk && b->ntb_b) {
-            hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_b_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_tblist + b->ntb + b->ntb_c, b->ntb_b, b->d_sync, b->d_trace, spin_limit, b->lq_off + njp, 8u);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
+        // (tracebacks beside the sweeps: what follows a sweep kernel on its CUs joins in — the jobs that are ready and not yet claimed, then pre-linking)
+        if (beside) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->nband_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        else if (tbk && b->ntb_b) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_b_workers), dim3(64 * PGM_WAVES), 0, ctx->stream3, b->d_jobs, b->d_tblist + b->ntb + b->ntb_c, b->ntb_b, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off + njp, 8u, 0u, 1u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(b->ev_join_b, ctx->stream3)) != hipSuccess) return e;
     }
     if (critk) {
-        if (tbk && b->ntb_c) {
-            hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist + b->ntb, b->ntb_c, b->d_sync, b->d_trace, spin_limit, b->lq_off + 2 * njp, 16u);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
+        if (beside) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        else if (tbk && b->ntb_c) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist + b->ntb, b->ntb_c, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off + 2 * njp, 16u, 0u, 1u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(b->ev_join_c, ctx->stream4)) != hipSuccess) return e;
     }
-    if (tbk && b->ntb) {
+    if (beside && nrest != 0) {
+        hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else if (!beside && tbk && b->ntb) {
         // the tracebacks of the fill kernel's jobs, behind it on its stream
-        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off, 0u);
-        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, spin_limit, b->lq_off, 0u);
+        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
+        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (beside && (e = hipStreamWaitEvent(s, b->ev_join_t, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(s, b->ev_join_b, 0)) != hipSuccess) return e;
     if (critk && (e = hipStreamWaitEvent(s, b->ev_join_c, 0)) != hipSuccess) return e;
     if (fork && ((e = hipEventRecord(b->ev_join, ctx->stream2)) != hipSuccess || (e = hipStreamWaitEvent(s, b->ev_join, 0)) != hipSuccess)) return e;
@@ -722,10 +745,10 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
 extern "C" {
 
 int pgm_test_cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double band_cost, uint32_t nbands, double rest_cost, uint32_t nrest,
-                       uint32_t ncrit, double longest_chain, uint32_t *out4) {
-    if (!out4) return fail(PGM_ERR_INVALID, "null argument");
-    const CuShares r = cu_shares(cus, lean_cost, nlean, band_cost, nbands, rest_cost, nrest, ncrit, longest_chain);
-    out4[0] = r.lean; out4[1] = r.band; out4[2] = r.crit; out4[3] = r.rest;
+                       uint32_t ncrit, double longest_chain, double tb_cost, uint32_t ntb, uint32_t *out5) {
+    if (!out5) return fail(PGM_ERR_INVALID, "null argument");
+    const CuShares r = cu_shares(cus, lean_cost, nlean, band_cost, nbands, rest_cost, nrest, ncrit, longest_chain, tb_cost, ntb);
+    out5[0] = r.lean; out5[1] = r.band; out5[2] = r.crit; out5[3] = r.rest; out5[4] = r.tb;
     return PGM_OK;
 }
 
@@ -806,6 +829,8 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     b->s_bytes = std::max<size_t>(L.SL.bytes, 16);
     b->lq_off = (uint32_t)L.sync_ints;                   // ids of the jobs whose tracebacks have started (pre-link announcements)
     L.sync_ints += 3 * (((size_t)njobs + 3) / 4 * 4);  // (one array per instance of pgm_tb_kernel)
+    b->tbq_off = (uint32_t)L.sync_ints;                  // ready queue of the traceback kernel that runs beside the sweeps
+    L.sync_ints += ((size_t)njobs + 3) / 4 * 4 + 4;
     const size_t sync_ints = L.sync_ints;
     b->sync_ints = sync_ints;
     hipError_t alloc_err = hipSuccess, alloc_host_err = hipSuccess;
@@ -871,6 +896,10 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         const bool no_helper = tools_env("PGM_NO_HELPER") != nullptr;
         const int mode2_min_bands = tools_env("PGM_MODE2_BANDS") ? atoi(tools_env("PGM_MODE2_BANDS")) : 20;   // tools build only
         const uint32_t mode2_min_hd = tools_env("PGM_MODE2_HD") ? (uint32_t)atoi(tools_env("PGM_MODE2_HD")) : 32u;
+        // (the chain of sweeps the batch's largest job would have in pgm_crit_kernel, from the sizes alone: what the other jobs' chains are held against)
+        double longest_crit_chain = 0.0;
+        for (uint32_t i = 0; i < njobs; ++i)
+            longest_crit_chain = std::max(longest_crit_chain, ((double)((g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS - 1) * 80.0 + (double)(g2[i]->n - 1 + 63)) * 0.42);
         const uint32_t chunk_jobs = (uint32_t)std::max<size_t>(1, ((size_t)8 << 20) / std::max<size_t>(1, in_base[njobs] / std::max(1u, njobs)));
         std::vector<std::atomic<uint32_t>> chunk_done((njobs + chunk_jobs - 1) / chunk_jobs + 1);
         for (auto &cd : chunk_done) cd.store(0);
@@ -898,7 +927,15 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 // (the helpers address the job's cell storage with 32-bit byte offsets)
                 const bool allow_long = !tools_env("PGM_NO_LONG") && (uint64_t)J.nb * J.tsteps * 1024u < (1ull << 32);
                 const bool has_long = (o.s1.has_long | o.s2.has_long) != 0 && allow_long;
-                J.mode2 = (J.has_extras && (hD >= mode2_min_hd || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
+                // (a job whose self-contained sweep fits a quarter of the LDS and that is not on the critical path — fewer than 20 bands —
+                // goes to pgm_band_kernel's WIDE workers, four bands per CU, instead of one band per CU with helper wavefronts)
+                // ... provided its chain of self-contained sweeps (slower per step the more of its nodes have far edges: 0.75 us at none,
+                // 1 us at 2.5 %, measured on levels 4 and 5 of the headline family) still ends well before the batch's longest chain
+                const uint32_t slot1 = 2u * hD * (64u + PGM_VL) * 4u + hDX * 64u * 4u + PGM_NRING * 48u;
+                const double far_density = 0.5 * ((double)o.s1.cp[g1[i]->n] / g1[i]->n + (double)o.s2.cp[g2[i]->n] / g2[i]->n);
+                const double chain_wide = ((double)(nb_job - 1) * 78.0 + (double)(g2[i]->n - 1 + 63)) * (0.7 + 10.0 * far_density);
+                const bool fits_wide = slot1 <= (uint32_t)(PGM_POOL / PGM_WIDE_WAVES / 16 * 16) && chain_wide <= 0.9 * longest_crit_chain && !tools_env("PGM_NO_WIDE");
+                J.mode2 = (J.has_extras && ((hD >= mode2_min_hd && !fits_wide) || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
                 if (J.mode2) {   // (a MODE 2 sweep keeps every on-chip distance of the graphs, whatever the number of entries of a node)
                     while (hD < o.s1.maxd_cap + o.s2.maxd_cap + (uint32_t)PGM_BLOCK) hD *= 2;
                     while (hDX < o.s2.maxd_cap + 1) hDX *= 2;
@@ -1050,17 +1087,17 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     std::vector<PgmItem> bands;   // pgm_band_kernel's list: one band per entry
     if (njobs) {
         struct Item { double rem, dur, gap; uint32_t job, band, count; };
-        std::vector<std::vector<Item>> per_job(njobs), per_job_b(njobs), per_job_c(njobs);
+        std::vector<std::vector<Item>> per_job(njobs), per_job_b(njobs), per_job_c(njobs), per_job_w(njobs);   // main launch, narrow bands, longest chains, wide bands
         std::vector<double> chain_of(njobs, 0.0);   // chain of sweeps of the jobs of the fill kernel
         const double lag = PGM_ROWS + 3.0 * PGM_BLOCK;
         auto envd = [](const char *k, double d) { const char *v = tools_env(k); return v ? atof(v) : d; };   // tools build only
         const double tau_x = envd("PGM_SIM_TAU_X", 0.65), tau_c = envd("PGM_SIM_TAU_C", 0.45), tau_2 = envd("PGM_SIM_TAU_2", 0.6), eager = envd("PGM_SIM_EAGER", 0.7);
         const double tau_3 = envd("PGM_SIM_TAU_3", 0.42);   // a band of a crit3 job (pgm_crit_kernel)
-        const double tau_l = envd("PGM_SIM_TAU_L", 0.27);   // lean sweep: us per step of R rows per lane
+        const double tau_l = envd("PGM_SIM_TAU_L", 0.34);   // lean sweep: us per step of R rows per lane
         // The jobs without helper wavefronts go to pgm_band_kernel, band by band (not with the timeline of the tools build, whose
         // slots are the fill kernel's items, and not a job whose sweep would not fit an eighth of the LDS)
         const bool use_bands = !tools_env("PGM_FILL_TRACE") && !tools_env("PGM_NO_BANDK");
-        size_t total = 0, total_b = 0;
+        size_t total = 0, total_b = 0, total_w = 0;
         double rmax = 1.0, rsweep = 1.0;   // longest remaining path with / without the traceback behind it
         for (uint32_t q = 0; q < njobs; ++q) {
             const uint32_t i = b->order[q];   // (largest first: the order of the lean queue)
@@ -1073,7 +1110,9 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 lean_list.push_back(i);
                 continue;
             }
-            const bool per_band = use_bands && !J.mode2 && J.slot_bytes <= (uint32_t)(PGM_POOL / PGM_WAVES / 16 * 16);
+            const bool narrow = use_bands && !J.mode2 && J.slot_bytes <= (uint32_t)(PGM_POOL / PGM_WAVES / 16 * 16);
+            const bool wide = use_bands && !J.mode2 && !narrow && J.slot_bytes <= (uint32_t)(PGM_POOL / PGM_WIDE_WAVES / 16 * 16);
+            const bool per_band = narrow || wide;
             if (!per_band) chain_of[i] = tau * ((double)(J.nb - 1) * lag + J.tsteps);
             const uint32_t group = per_band ? 1u : J.nslots;       // bands per item, one per wavefront of the worker
             for (uint32_t band = 0; band < J.nb; band += group) {
@@ -1083,12 +1122,13 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 it.dur = tau * ((double)(cnt - 1) * lag + J.tsteps);   // (the traceback is another kernel's: pgm_tb_kernel)
                 it.gap = tau * (double)cnt * lag;                 // the next item may start this long after this one
                 it.job = i; it.band = band; it.count = cnt;
-                (per_band ? per_job_b : per_job)[i].push_back(it);
+                (wide ? per_job_w : (narrow ? per_job_b : per_job))[i].push_back(it);
                 rmax = std::max(rmax, it.rem);
                 rsweep = std::max(rsweep, it.rem - tb);
             }
             total += per_job[i].size();
             total_b += per_job_b[i].size();
+            total_w += per_job_w[i].size();
         }
         // The CUs are split between the kernels (one worker per CU in each), see cu_shares(): the jobs with the longest chains of
         // sweeps (within 15 % of the longest: the root of a guide tree, as a rule) get a launch of the fill kernel of their own, one CU
@@ -1096,7 +1136,13 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         // way before they start (each launch is followed by its own instance of pgm_tb_kernel); only if other jobs stay behind for
         // the main launch.  The rest of the CUs is dealt to the lean queue, the band queue and the main launch by their costs.
         double band_cost = 0.0, crit_cost = 0.0;
-        for (uint32_t i = 0; i < njobs; ++i) { for (const Item &it : per_job[i]) other_cost += it.dur; for (const Item &it : per_job_b[i]) band_cost += it.dur / PGM_WAVES; }
+        double wide_cost = 0.0;
+        for (uint32_t i = 0; i < njobs; ++i) {
+            for (const Item &it : per_job[i]) other_cost += it.dur;
+            for (const Item &it : per_job_b[i]) band_cost += it.dur / PGM_WAVES;
+            for (const Item &it : per_job_w[i]) wide_cost += it.dur / PGM_WIDE_WAVES;
+        }
+        band_cost += wide_cost;   // one queue for the shares: pgm_band_kernel's workers, split below
         size_t total_c = 0;
         if (use_bands && total != 0) {
             uint32_t ncj = 0, nrestj = 0;
@@ -1105,17 +1151,30 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 for (uint32_t i = 0; i < njobs; ++i)
                     if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) { total_c += per_job[i].size(); for (const Item &it : per_job[i]) crit_cost += it.dur; }
         }
-        CuShares sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)total_b, other_cost - crit_cost, (uint32_t)(total - total_c), (uint32_t)total_c, rsweep);
+        // the tracebacks of the jobs of the fill, crit and band kernels run beside the sweeps on CUs of their own (not with the timeline
+        // of the tools build, whose slots belong to the kernels that follow each other)
+        double tb_cost = 0.0;
+        uint32_t ntb_all = 0;
+        // (measured on the headline batch, round 4: the jobs of a guide-tree level end together, late in the stage — beside the sweeps the
+        // workers of this kernel idle until then, and the root's walk loses the pre-linkers that the launch of the longest chains hands it
+        // when its tracebacks follow it: 3.3 ms against 2.9.  Kept for batches whose jobs end at different times: PGM_TB_BESIDE=1.)
+        const bool tb_beside = getenv("PGM_TB_BESIDE") != nullptr && !tools_env("PGM_FILL_TRACE") && !tools_env("PGM_NO_TBK") && !tools_env("PGM_FILL_DBG");
+        for (uint32_t i = 0; i < njobs; ++i) if (!b->jobs[i].lean) { ++ntb_all; tb_cost += (b->jobs[i].has_extras ? 0.3 : 0.2) * (double)(b->jobs[i].n1 + b->jobs[i].n2); }
+        if (!tb_beside) { ntb_all = 0; tb_cost = 0.0; }
+        CuShares sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)(total_b + 2 * total_w), other_cost - crit_cost, (uint32_t)(total - total_c), (uint32_t)total_c, rsweep, tb_cost, ntb_all);
         if (total_c != 0 && sh.crit == 0) {   // no CU to spare for a launch of their own: the longest chains stay in the main launch
             total_c = 0; crit_cost = 0.0;
-            sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)total_b, other_cost, (uint32_t)total, 0u, rsweep);
+            sh = cu_shares(capacity, lean_cost, (uint32_t)lean_list.size(), band_cost, (uint32_t)(total_b + 2 * total_w), other_cost, (uint32_t)total, 0u, rsweep, tb_cost, ntb_all);
         }
+        b->ntb_beside_workers = sh.tb;
         if (total_c != 0)
             for (uint32_t i = 0; i < njobs; ++i)
                 if (!per_job[i].empty() && chain_of[i] >= 0.85 * rsweep) per_job_c[i].swap(per_job[i]);
         total -= total_c;
         const double t_goal = sh.t_goal;
         uint32_t lean_cus = sh.lean, band_cus = sh.band, crit_cus = sh.crit;
+        // (a lean job is one worker's: the queue ends after ceil(jobs / workers) rounds — the fewest workers with that many rounds do)
+        if (lean_cus) { const uint32_t rounds = ((uint32_t)lean_list.size() + lean_cus - 1u) / lean_cus; lean_cus = ((uint32_t)lean_list.size() + rounds - 1u) / rounds; }
         if (const char *v = tools_env("PGM_LEAN_CUS")) if (lean_cus) lean_cus = std::max(1u, std::min(std::min(capacity - 1u, (uint32_t)lean_list.size()), (uint32_t)atoi(v)));
         b->nlean = (uint32_t)lean_list.size();
         b->nlean_workers = lean_cus;
@@ -1153,23 +1212,59 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
             return end;
         };
         double band_end = 0.0;
-        if (total_b != 0) {
+        uint32_t wide_cus = 0;
+        std::vector<PgmItem> bands_w;
+        if (total_b + total_w != 0) {
             // (a simulation of a 1000-band list is 0.1 ms: the share grows by how far the simulated schedule overshoots, three times at
-            // most, and only into CUs the main launch does not need for its own share)
+            // most, and only into CUs the main launch does not need for its own share).  The share is split between the workers of
+            // the narrow bands (eight at a time per CU) and of the wide ones (four at a time) by their work.
             const uint32_t most = std::max(band_cus, band_cus + (sh.rest > sh.rest_need ? sh.rest - sh.rest_need : 0u));
+            auto split = [&](uint32_t cus) {
+                if (total_w == 0) return 0u;
+                if (total_b == 0) return cus;
+                const uint32_t w = (uint32_t)std::lround(cus * wide_cost / band_cost);
+                return std::max(1u, std::min(cus > 1u ? cus - 1u : 1u, w));
+            };
+            auto run = [&](uint32_t cus) {
+                wide_cus = split(cus);
+                const uint32_t ncus = cus > wide_cus ? cus - wide_cus : (total_b ? 1u : 0u);
+                double e = 0.0;
+                if (total_b) e = simulate(per_job_b, total_b, ncus * PGM_WAVES, bands);
+                if (total_w) e = std::max(e, simulate(per_job_w, total_w, wide_cus * PGM_WIDE_WAVES, bands_w));
+                return e;
+            };
             if (const char *v = tools_env("PGM_BAND_CUS")) band_cus = std::max(1u, std::min(most, (uint32_t)atoi(v)));
             else if (total != 0) {
                 for (int it = 0; it < 3 && band_cus < most; ++it) {
-                    band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
+                    band_end = run(band_cus);
                     if (band_end <= sh.fb * t_goal) break;
                     band_cus = std::min(most, std::max(band_cus + 1u, (uint32_t)std::ceil(band_cus * std::min(2.0, band_end / (sh.fb * t_goal)))));
                 }
             }
-            band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES)));
-            band_end = simulate(per_job_b, total_b, band_cus * PGM_WAVES, bands);
+            band_cus = std::max(1u, std::min<uint32_t>(std::min(band_cus, most), (uint32_t)((total_b + PGM_WAVES - 1) / PGM_WAVES + (total_w + PGM_WIDE_WAVES - 1) / PGM_WIDE_WAVES)));
+            if (total_b && total_w) band_cus = std::max(band_cus, 2u);
+            band_end = run(band_cus);
+            if (total_b == 0) bands.clear();
+            b->nbands_narrow = (uint32_t)(total_b ? bands.size() : 0);
+            bands.insert(bands.end(), bands_w.begin(), bands_w.end());
         }
+        if (total_b + total_w != 0 && !tools_env("PGM_BAND_CUS")) {
+            // the tracebacks of the band kernel's jobs follow it on its CUs, one worker per job: with fewer workers than jobs the last ones
+            // wait a whole walk longer — a round less if the main launch can spare the CUs for it
+            uint32_t nbj = 0;
+            for (uint32_t i = 0; i < njobs; ++i) nbj += (!per_job_b[i].empty() || !per_job_w[i].empty());
+            const uint32_t most = std::max(band_cus, band_cus + (sh.rest > sh.rest_need ? sh.rest - sh.rest_need : 0u));
+            if (nbj > band_cus) {
+                const uint32_t rounds = (nbj + band_cus - 1u) / band_cus, want = rounds > 1u ? (nbj + rounds - 2u) / (rounds - 1u) : band_cus;
+                if (want > band_cus && want <= most && want <= band_cus + band_cus / 8u + 1u) {
+                    band_cus = want;
+                    wide_cus = total_w == 0 ? 0u : (total_b == 0 ? band_cus : std::max(1u, std::min(band_cus - 1u, (uint32_t)std::lround(band_cus * wide_cost / band_cost))));
+                }
+            }
+        }
+        b->nwide_workers = wide_cus;
         b->nband_workers = band_cus;
-        capacity = std::max(1u, capacity > lean_cus + band_cus + crit_cus ? capacity - lean_cus - band_cus - crit_cus : 1u);   // the main launch's CUs
+        capacity = std::max(1u, capacity > lean_cus + band_cus + crit_cus + sh.tb ? capacity - lean_cus - band_cus - crit_cus - sh.tb : 1u);   // the main launch's CUs
         b->ncrit_workers = crit_cus;
         std::vector<PgmItem> items_rest;
         const double crit_end = total_c ? simulate(per_job_c, total_c, crit_cus, items) : 0.0;
@@ -1235,6 +1330,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     (void)hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&b->ev_join_b, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&b->ev_join_c, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&b->ev_join_t, hipEventDisableTiming);
     if (cprof)
         fprintf(stderr, "    create: sizes %.2f ms, pinned input block %.2f, flatten %.2f, wait for the allocations %.2f (device %.2f, pinned results %.2f), work list %.2f, upload of %.1f MB %.2f\n",
                 tc0 - tcs, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc_alloc, tc_hostalloc, tc4 - tc3, b->in_bytes / 1e6, now_ms() - tc4);
@@ -1411,12 +1507,14 @@ void pgm_align_batch_destroy(pgm_ctx *ctx, pgm_align_batch *b) {
     if (ctx && ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx && ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     if (ctx && ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
+    if (ctx && ctx->stream5) (void)hipStreamSynchronize(ctx->stream5);
     for (int k = 0; k < 5; ++k)
         if (b->ev[k]) (void)hipEventDestroy(b->ev[k]);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     if (b->ev_join_b) (void)hipEventDestroy(b->ev_join_b);
     if (b->ev_join_c) (void)hipEventDestroy(b->ev_join_c);
+    if (b->ev_join_t) (void)hipEventDestroy(b->ev_join_t);
     cache_give(ctx, pgm_ctx::C_IN, b->d_in, b->cap[pgm_ctx::C_IN]);
     cache_give(ctx, pgm_ctx::C_WORK, b->d_work, b->cap[pgm_ctx::C_WORK]);
     cache_give(ctx, pgm_ctx::C_CELLS, b->d_cells, b->cap[pgm_ctx::C_CELLS]);

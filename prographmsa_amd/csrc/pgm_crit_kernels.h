@@ -750,7 +750,7 @@ __device__ __forceinline__ void pgm_crit_rows(const PgmJob &J, const uint32_t b,
 template <bool DBG>
 __global__ void __launch_bounds__(64 * PGM_C3_WAVES, 1) pgm_crit_kernel(const PgmJob *__restrict__ jobs, const PgmItem *__restrict__ items, uint32_t nitems,
                                                                      int *__restrict__ sync, uint32_t spin_limit, uint32_t stall_job, uint32_t stall_band, uint32_t ticket_off,
-                                                                     unsigned long long *__restrict__ dbg_) {
+                                                                     unsigned long long *__restrict__ dbg_, uint32_t tbq_off) {
     int *abort_flag = sync;
     __shared__ __attribute__((aligned(16))) struct { uint8_t pool[PGM_POOL]; } L;
     __shared__ int item_lds;
@@ -809,7 +809,7 @@ __global__ void __launch_bounds__(64 * PGM_C3_WAVES, 1) pgm_crit_kernel(const Pg
             if (threadIdx.x == 0) J.times[0] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // an aborted batch leaves its records here
                 J.result->score = 0.f; J.result->n_tr_indels = 0; J.result->len = 0; J.result->status = PGM_ERR_DEVICE; J.hresult->score = 0.f; J.hresult->n_tr_indels = 0; J.hresult->len = 0; __threadfence_system(); __hip_atomic_store(&J.hresult->status, (int32_t)PGM_ERR_DEVICE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            } else if (threadIdx.x == 0) pgm_tbq_push(sync, tbq_off, item.job);
         }
     }
 }

@@ -16,6 +16,7 @@
 #define PGM_PF 4           /* MODE 2: the far helpers load the sources of long / remote entries this many steps ahead */
 #define PGM_REMOTE_MAX 128 /* MODE 2: remote row entries per band served by the row helpers (passes 0 and 1) */
 #define PGM_WAVES 8        /* wavefronts of a fill worker (one 512-thread workgroup per CU) */
+#define PGM_WIDE_WAVES 4    /* pgm_band_kernel: sweeping wavefronts of a WIDE worker (sweeps whose history needs a quarter of the CU's LDS) */
 #define PGM_POOL 163584    /* LDS bytes of a fill worker (one worker per CU: 163584 + 256 = 160 KiB) */
 #define PGM_CPARTS 3       /* MODE 2: far helpers of the ROWS (row entry passes p = part + 3 q), 2 each for the near terms and the columns */
 /* extra LDS of a MODE 2 sweep (PgmJob::mode2: seven helper wavefronts evaluate all but the chain terms), at PgmJob::aux_off: */
@@ -180,9 +181,11 @@ struct PgmJob {
 // words of the batch's sync block the traceback kernel polls (a cache line of their own; [0] abort flag, [1] / [2] the tickets of the band and lean lists)
 #define PGM_SY_BAND_TICKET 3  // ticket counter of pgm_band_kernel's list (with the other tickets in the first cache line)
 #define PGM_SY_CRIT_TICKET 4  // ticket counter of the fill kernel's second launch (the jobs with the longest chains of sweeps)
+#define PGM_SY_WIDE_TICKET 5  // ticket counter of pgm_band_kernel's wide bands
 #define PGM_SY_LQ_N 32      // tracebacks that have started (pre-link announcements, ids in lq_ids)
 #define PGM_SY_TB_DONE 33   // tracebacks finished
 #define PGM_SY_TBQ_N 34     // ticket counter of the traceback kernel's job list
+#define PGM_SY_TBQ_TAIL 35  // jobs in the ready queue of the traceback kernel that runs beside the sweeps
 #define PGM_LK_W 4u        // grid tiles per grid row in the corridor around the diagonal (paths of the headline batch stay within 40 columns of it)
 #define PGM_LK_T 32u       // tile edge
 #define PGM_LK_NR 4u       // grid rows of tables a walker keeps in LDS (fetched together when known to be complete)

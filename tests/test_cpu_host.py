@@ -41,28 +41,34 @@ def test_cu_shares_never_starve_a_launch():
     band-heavy shape that once left the main launch and the longest chains with a grid of zero (round-3 review)."""
     import ctypes as C
     import prographmsa_amd as pg
-    out = (C.c_uint32 * 4)()
+    out = (C.c_uint32 * 5)()
 
-    def shares(cus, lean, nlean, band, nbands, rest, nrest, ncrit, chain):
-        pg.check(pg.lib.pgm_test_cu_shares(cus, lean, nlean, band, nbands, rest, nrest, ncrit, chain, out))
-        l, b, c, r = list(out)
-        assert l + b + c + r <= max(cus, (nlean > 0) + (nbands > 0) + (nrest > 0)), (l, b, c, r)
-        assert (l > 0) == (nlean > 0) and (b > 0) == (nbands > 0) and (r > 0) == (nrest > 0), (l, b, c, r)
+    def shares(cus, lean, nlean, band, nbands, rest, nrest, ncrit, chain, tb=0., ntb=0):
+        pg.check(pg.lib.pgm_test_cu_shares(cus, lean, nlean, band, nbands, rest, nrest, ncrit, chain, tb, ntb, out))
+        l, b, c, r, t = list(out)
+        assert l + b + c + r + t <= max(cus, (nlean > 0) + (nbands > 0) + (nrest > 0) + (ntb > 0)), (l, b, c, r, t)
+        assert (l > 0) == (nlean > 0) and (b > 0) == (nbands > 0) and (r > 0) == (nrest > 0) and (t > 0) == (ntb > 0), (l, b, c, r, t)
         assert c <= ncrit and c <= cus // 2
-        return l, b, c, r
+        return l, b, c, r, t
 
     # the headline batch with a fast longest chain (1.8 ms) is bound by throughput: the shares follow the work
-    l, b, c, r = shares(256, 64392., 128, 138987., 1579, 226000., 496, 35, 1824.)
-    assert c == 35 and l + b + r == 221 and abs(r - 221 * 226000. / 429379.) <= 3, (l, b, c, r)
+    l, b, c, r, t = shares(256, 64392., 128, 138987., 1579, 226000., 496, 35, 1824.)
+    assert c == 35 and t == 0 and l + b + r == 221 and abs(r - 221 * 226000. / 429379.) <= 3, (l, b, c, r)
+    # ... with the tracebacks beside the sweeps: a share of their own for the early finishers (a third of their work over the goal)
+    l, b, c, r, t = shares(256, 64392., 128, 138987., 1579, 226000., 496, 35, 1824., 80000., 127)
+    assert c == 35 and 10 <= t <= 16 and l + b + r + t == 221, (l, b, c, r, t)
     # a batch bound by its longest chain: the other launches end early, the main launch keeps the rest
-    l, b, c, r = shares(256, 64392., 128, 138987., 1579, 100000., 496, 35, 3300.)
+    l, b, c, r, t = shares(256, 64392., 128, 138987., 1579, 100000., 496, 35, 3300.)
     assert c == 35 and l <= 64392. / (0.6 * 3300.) + 1 and b <= 138987. / (0.75 * 3300.) + 1 and r >= 100
     # band-heavy batch, two MODE 2 jobs on either side of the cut: nobody is left with a grid of zero
-    l, b, c, r = shares(256, 0., 0, 2.0e6, 20000, 3000., 40, 25, 900.)
-    assert b >= 200 and r >= 1 and c >= 1
+    l, b, c, r, t = shares(256, 0., 0, 2.0e6, 20000, 3000., 40, 25, 900., 5000., 300)
+    assert b >= 150 and r >= 1 and c >= 1 and t >= 1
+    # one job alone: a worker for its traceback beside its sweeps
+    l, b, c, r, t = shares(256, 0., 0, 0., 0, 30000., 35, 0, 2000., 1300., 1)
+    assert r == 35 and t == 1
     # tiny devices and tiny batches
     for cus in (1, 2, 3, 4, 8):
-        shares(cus, 100., 3, 100., 30, 100., 5, 4, 50.)
+        shares(cus, 100., 3, 100., 30, 100., 5, 4, 50., 40., 7)
         shares(cus, 0., 0, 0., 0, 100., 5, 0, 50.)
         shares(cus, 100., 3, 0., 0, 0., 0, 0, 1.)
     assert shares(256, 100., 128, 0., 0, 0., 0, 0, 1.)[0] == 128
