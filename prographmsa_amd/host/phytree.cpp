@@ -1,8 +1,7 @@
 // phytree.cpp — guide-tree container, newick reader/writer and FASTA IO
 // (reference src/PhyTree.{h,cpp}, src/newick.cpp, src/Fasta.cpp).  Host scaffolding only.
-// NOTE: maxDistPairR / midpointRoot below are DERIVED FROM reference src/PhyTree.cpp:11-116 (statement-for-statement restatement,
-// identifiers kept): host scaffolding outside SURVEY §8, needed only so that a FASTA / newick artefact can be produced
-// for the parity tests; it earns no coverage credit.
+// Midpoint rooting reproduces the behaviour of reference src/PhyTree.cpp:11-116 (same longest pair among ties, same child order of
+// the re-rooted tree: the newick must come out byte for byte) in this mirror's own terms; host scaffolding outside SURVEY §8.
 #include "pgm_host.h"
 
 #include <algorithm>
@@ -68,69 +67,81 @@ std::string PhyTree::formatNewickR() const {  // PhyTree.h:41-55 (default ostrea
 }
 std::string PhyTree::formatNewick() const { return formatNewickR() + ";"; }
 
-// ---- midpoint rooting (PhyTree.cpp:11-116) -------------------------------------------------
-static void maxDistPairR(const PhyTree *root, std::vector<double> &distances, std::vector<const PhyTree *> &leaves,
-                         const PhyTree *&max, double &max_dist) {
-    if (!root->isLeaf()) {
-        if (root->n_children() != 2) error("multifurcations not supported");
-        std::vector<double> distances2;
-        std::vector<const PhyTree *> leaves2;
-        maxDistPairR(&(*root)[0], distances, leaves, max, max_dist);
-        maxDistPairR(&(*root)[1], distances2, leaves2, max, max_dist);
-        for (double &d : distances) d += (*root)[0].getBranchLength();
-        for (double &d : distances2) d += (*root)[1].getBranchLength();
-        for (size_t i = 0; i < distances.size(); ++i)
-            for (size_t j = 0; j < distances2.size(); ++j)
-                if (distances[i] + distances2[j] > max_dist) {
-                    max_dist = distances[i] + distances2[j];
-                    max = distances[i] > distances2[j] ? leaves[i] : leaves2[j];
-                }
-        distances.insert(distances.end(), distances2.begin(), distances2.end());
-        leaves.insert(leaves.end(), leaves2.begin(), leaves2.end());
-    } else {
-        distances.push_back(0);
-        leaves.push_back(root);
+// ---- midpoint rooting (behaviour of PhyTree.cpp:11-116: the newick of the re-rooted tree must come out byte for byte) ----
+// Own formulation.  The leaves are numbered in depth-first order, so the leaves of a subtree are one contiguous range of the
+// array `depth` (distance of the leaf to the root of the subtree being finished); an internal node adds its two branch lengths to
+// its children's ranges and compares every leaf of the first child with every leaf of the second, first child's leaf outermost —
+// the same visiting order, hence the same winner among equal path lengths, as the reference's recursion.  The winner of a pair is
+// its deeper leaf: the walk to the midpoint starts there.
+namespace {
+struct LeafSpan { size_t lo, hi; };
+
+struct Diameter {
+    std::vector<double> depth;
+    std::vector<const PhyTree *> leaf;
+    double longest = -INFINITY;
+    const PhyTree *deep_end = nullptr;
+
+    LeafSpan finish(const PhyTree *node) {
+        if (node->isLeaf()) {
+            depth.push_back(0.0);
+            leaf.push_back(node);
+            return LeafSpan{depth.size() - 1, depth.size()};
+        }
+        if (node->n_children() != 2) error("multifurcations not supported");
+        const LeafSpan first = finish(&(*node)[0]), second = finish(&(*node)[1]);
+        const double len0 = (*node)[0].getBranchLength(), len1 = (*node)[1].getBranchLength();
+        for (size_t k = first.lo; k < first.hi; ++k) depth[k] += len0;
+        for (size_t k = second.lo; k < second.hi; ++k) depth[k] += len1;
+        for (size_t p = first.lo; p < first.hi; ++p)
+            for (size_t q = second.lo; q < second.hi; ++q) {
+                const double path = depth[p] + depth[q];
+                if (path > longest) { longest = path; deep_end = depth[p] > depth[q] ? leaf[p] : leaf[q]; }
+            }
+        return LeafSpan{first.lo, second.hi};
     }
-}
+};
+}  // namespace
 
 PhyTree *midpointRoot(PhyTree *root) {
-    const PhyTree *max = nullptr;
-    std::vector<double> distances;
-    std::vector<const PhyTree *> leaves;
-    double dist = -INFINITY;
-    maxDistPairR(root, distances, leaves, max, dist);
-    PhyTree *current = const_cast<PhyTree *>(max);
-    dist /= 2;
-    while (current != root && dist - current->getBranchLength() > 0) {
-        dist -= current->getBranchLength();
-        current = current->getParent();
+    Diameter dia;
+    dia.finish(root);
+    // climb from the deeper end of the longest path until half of it is used up: the midpoint lies on the branch above `below`
+    PhyTree *below = const_cast<PhyTree *>(dia.deep_end);
+    double remaining = dia.longest / 2;
+    while (below != root && remaining - below->getBranchLength() > 0) {
+        remaining -= below->getBranchLength();
+        below = below->getParent();
     }
-    if (current == root) return root;
+    if (below == root) return root;
 
-    PhyTree *new_root = new PhyTree("new_root");
-    double current_dist = current->getBranchLength() - dist;
-    double current_support = current->getBranchSupport();
-    PhyTree *parent = current->getParent();
-    current->pluck();
-    new_root->addChild(current, dist, current_support);
-    current = new_root;
-    while (parent != root) {
-        double new_dist = parent->getBranchLength();
-        double new_support = parent->getBranchSupport();
-        PhyTree *new_parent = parent->getParent();
-        parent->pluck();
-        current->addChild(parent, current_dist, current_support);
-        current = parent;
-        parent = new_parent;
-        current_dist = new_dist;
-        current_support = new_support;
+    // the nodes from the midpoint branch's upper end up to (not including) the old root, with the branch each hangs on
+    struct Hop { PhyTree *node; double length, support; };
+    std::vector<Hop> climb;
+    for (PhyTree *n = below->getParent(); n != root; n = n->getParent()) climb.push_back(Hop{n, n->getBranchLength(), n->getBranchSupport()});
+
+    PhyTree *fresh = new PhyTree("new_root");
+    const double upper_part = below->getBranchLength() - remaining, upper_support = below->getBranchSupport();
+    below->pluck();
+    fresh->addChild(below, remaining, upper_support);
+    // turn the climb upside down: every node on it becomes the last child of the node that was below it, on the branch that node
+    // used to hang on
+    PhyTree *attach_to = fresh;
+    double hang_length = upper_part, hang_support = upper_support;
+    for (const Hop &h : climb) {
+        h.node->pluck();
+        attach_to->addChild(h.node, hang_length, hang_support);
+        attach_to = h.node;
+        hang_length = h.length;
+        hang_support = h.support;
     }
-    current_dist += (*root)[0].getBranchLength();
-    current_support = std::max(current_support, (*root)[0].getBranchSupport());
-    PhyTree *other = root->pluckChild(0);
-    current->addChild(other, current_dist, current_support);
+    // the old root disappears: its remaining child continues the last branch
+    const PhyTree &sibling = (*root)[0];   // (the climb's top node, or `below` itself, has been plucked: one child is left)
+    const double merged_length = hang_length + sibling.getBranchLength();
+    const double merged_support = std::max(hang_support, sibling.getBranchSupport());
+    attach_to->addChild(root->pluckChild(0), merged_length, merged_support);
     delete root;
-    return new_root;
+    return fresh;
 }
 
 static void get_tree_order_rec(const PhyTree *tree, std::vector<std::string> &order) {
