@@ -120,6 +120,7 @@ int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *con
 typedef struct pgm_site_ref {
     const double *dev_sites;
     const uint32_t *node_map; /* host array, n entries */
+    uint32_t ncols;           /* columns of the device matrix: every node_map[v] (or n itself, without a map) must stay below it — PGM_ERR_INVALID otherwise */
 } pgm_site_ref;
 int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                                const pgm_graph *const *g2, const pgm_model *const *model,

@@ -50,7 +50,7 @@ class pgm_merge_job(C.Structure):
 
 
 class pgm_site_ref(C.Structure):
-    _fields_ = [("dev_sites", C.POINTER(C.c_double)), ("node_map", C.POINTER(C.c_uint32))]
+    _fields_ = [("dev_sites", C.POINTER(C.c_double)), ("node_map", C.POINTER(C.c_uint32)), ("ncols", C.c_uint32)]
 
 
 class pgm_align_out(C.Structure):

@@ -368,6 +368,9 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     if (pc.empty()) { pc.push_back(0); pv.push_back(0); pu.push_back(0); }
     o.smap = 0; o.has_smap = false;
     if (resident) {   // the profiles are in HBM already (pgm_merge_profiles_batch_ex): only the node -> column map travels
+        // (the prep kernel gathers column node_map[v] of the device matrix unchecked: the range is checked here)
+        if (res->ncols == 0 || (!res->node_map && n > res->ncols)) return PGM_ERR_INVALID;
+        if (res->node_map) for (uint32_t v = 0; v < n; ++v) if (res->node_map[v] >= res->ncols) return PGM_ERR_INVALID;
         o.sites = 0;
         if (res->node_map) { o.smap = A.put(res->node_map, 4 * (size_t)n); o.has_smap = true; }
     } else o.sites = A.put(g->sites, sizeof(double) * (size_t)g->dim * n);

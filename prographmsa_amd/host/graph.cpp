@@ -181,6 +181,7 @@ Graph SequenceGraphFromProfile(int dim, index_t nnodes, const std::vector<double
 // ---------------------------------------------------------------------------------------
 CleanedGraph::CleanedGraph(const Graph &original) : Graph(original) {  // CleanedGraph.h:39-146
     const index_t n = original.size();
+    original_size_ = n;
     std::vector<bool> marked_fw(n, false), marked_bw(n, false);
     std::vector<index_t> mapping(n, (index_t)-1);
     dp_score_t repeatExt = cmdlineopts.repeatext_prob == 0 ? (dp_score_t)INFINITY : 0;

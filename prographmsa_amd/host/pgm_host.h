@@ -207,9 +207,11 @@ public:
     explicit CleanedGraph(const Graph &original);
     index_t getMapping(index_t i) const { return outmapping_[i]; }
     const index_t *nodeMap() const { return outmapping_.data(); }   // node of the cleaned graph -> node of the original
+    index_t originalSize() const { return original_size_; }         // nodes of the original (columns of its profile matrix)
     void uncleanMapping(std::vector<index_t> &mapping) const;
 private:
     std::vector<index_t> outmapping_;
+    index_t original_size_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------

@@ -362,10 +362,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             bool any = false;
             for (size_t k = 0; k < L; ++k) any = any || pend[k].cg1->devSites() || pend[k].cg2->devSites();
             if (any) {
-                rs1.assign(L, pgm_site_ref{nullptr, nullptr}); rs2.assign(L, pgm_site_ref{nullptr, nullptr});
+                rs1.assign(L, pgm_site_ref{nullptr, nullptr, 0u}); rs2.assign(L, pgm_site_ref{nullptr, nullptr, 0u});
                 for (size_t k = 0; k < L; ++k) {
-                    if (pend[k].cg1->devSites()) rs1[k] = pgm_site_ref{pend[k].cg1->devSites(), pend[k].cg1->nodeMap()};
-                    if (pend[k].cg2->devSites()) rs2[k] = pgm_site_ref{pend[k].cg2->devSites(), pend[k].cg2->nodeMap()};
+                    if (pend[k].cg1->devSites()) rs1[k] = pgm_site_ref{pend[k].cg1->devSites(), pend[k].cg1->nodeMap(), (uint32_t)pend[k].cg1->originalSize()};
+                    if (pend[k].cg2->devSites()) rs2[k] = pgm_site_ref{pend[k].cg2->devSites(), pend[k].cg2->nodeMap(), (uint32_t)pend[k].cg2->originalSize()};
                 }
             }
         }

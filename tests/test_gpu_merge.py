@@ -152,8 +152,12 @@ def test_resident_profiles_through_merge_and_alignment(ctx):
     ref = J.align_graphs_batch(ctx, [job])[0]
     cj = J.CJobs([job])
     r1 = (pg.pgm_site_ref * 1)(); r2 = (pg.pgm_site_ref * 1)()
-    r1[0].dev_sites, r1[0].node_map = dev[0], P(map1, C.c_uint32)
-    r2[0].dev_sites, r2[0].node_map = dev[1], P(map2, C.c_uint32)
+    r1[0].dev_sites, r1[0].node_map, r1[0].ncols = dev[0], P(map1, C.c_uint32), h1.shape[1]
+    r2[0].dev_sites, r2[0].node_map, r2[0].ncols = dev[1], P(map2, C.c_uint32), h2.shape[1]
+    # a node map that points beyond the resident matrix is refused on the host (the device gathers unchecked)
+    r2[0].ncols = int(map2.max())
+    assert pg.lib.pgm_align_graphs_batch_res(ctx.handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out) == pg.PGM_ERR_INVALID
+    r2[0].ncols = h2.shape[1]
     pg.check(pg.lib.pgm_align_graphs_batch_res(ctx.handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out))
     got = cj.results()[0]
     assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
