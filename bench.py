@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-records (configs 4 / 5, 1024 x 600 all-pairs, strong scaling)")
     ap.add_argument("--only-headline", action="store_true", help="the timed loop over the headline batch and nothing else (profiling runs: every kernel launch of the process belongs to a step)")
+    ap.add_argument("--only-satellites", action="store_true", help="profiling runs: the all-pairs alignPair stage and the context-profile call of the headline family, nothing else timed")
+    ap.add_argument("--only-config", default=None, choices=["c4", "c5"], help="profiling runs: three passes over the jobs of BASELINE config 4 / 5 and nothing else")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no compute: only the launch / rendezvous / work-queue / aggregation plumbing (gloo), for CPU rehearsals")
     return ap.parse_args()
@@ -70,6 +72,8 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.only_satellites:
+        args.steps, args.warmup, args.no_extra, args.no_cpu_baseline = 1, 1, True, True
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +198,17 @@ def main():
         with open(os.path.join(tmp, "t.tree"), "w") as f:
             f.write(tr)
         tree_args = ["-t", os.path.join(tmp, "t.tree")]
+    if args.only_config:   # profiling runs (tools/profile_bench.sh): the jobs of one pass of BASELINE config 4 / 5, three launches
+        gold = os.path.join(ROOT, "tests", "golden")
+        text, flags = {"c4": (gen.fasta(gen.gen_codon(128, 1000, 4)), ["--codon", "--fasta", "-t", os.path.join(gold, "c4.tree")]),
+                       "c5": (gen.fasta(gen.gen(1024, 600, 6)), ["--fasta", "-t", os.path.join(gold, "c5.tree")])}[args.only_config]
+        js, st, md5 = capture(text, flags, args.only_config)
+        b2 = J.Batch(ctx, js)
+        for _ in range(3):
+            b2.run(); b2.fetch_raw()
+        print(json.dumps({"only_config": args.only_config, "jobs": len(js), "cells": b2.cells, "launches": 3, "ms": [round(v, 3) for v in b2.stage_times(reset=True)[:3]]}))
+        b2.close(); ctx.close()
+        return
     jobs, stats, out_md5 = capture(gen.fasta(fam), ["--fasta", "-m"] + tree_args, "c3")
     # the reference's default flow from sequences alone (`--fasta -a`: all-pairs guide tree, two rounds of progressive
     # alignment + guide-tree re-estimation, final alignment), rank 0 only; the FASTA's md5 is checked against the fixture of
@@ -237,19 +252,29 @@ def main():
     alg_bytes = 16.0 * cells            # one float4 {M,X,W,Y} store per cell; S is materialised by the emission
     achieved = alg_bytes / (ms_fill * 1e-3) / 1e9   # kernel, so this kernel also reads 4 B/cell that are not counted here
     # HBM traffic per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE, WRITE_SIZE in KB; gfx950: reads doubled)
-    traffic, pmc_name = None, "profiles/r3_pmc.json"
+    traffic, traffic_step, pmc_name = None, None, "profiles/r4_pmc.json"
     pmc_path = os.path.join(ROOT, pmc_name)
-    FILL_STAGE = ("pgm_fill_kernel", "pgm_band_kernel", "pgm_lean_kernel", "pgm_tb_kernel")   # the kernels between the events of the fill stage
+    FILL_STAGE = ("pgm_fill_kernel", "pgm_crit_kernel", "pgm_band_kernel", "pgm_lean_kernel", "pgm_tb_kernel")   # the kernels between the events of the fill stage
+    STEP = FILL_STAGE + ("pgm_prep_kernel", "pgm_emission_skew_kernel")
+
+    def pmc_bytes(allp, names):
+        """HBM bytes per step of the kernels `names` in a profiled run: 2 x FETCH_SIZE (gfx950 counts half of a streaming read) + WRITE_SIZE."""
+        steps_prof = float(allp.get("_steps", 0))
+        kb = 0.0
+        for k, v in allp.items():
+            if isinstance(v, dict) and k.startswith(names) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                kb += 2.0 * v["FETCH_SIZE"]["total_kb"] + v["WRITE_SIZE"]["total_kb"]
+        return round(kb * 1024.0 / steps_prof) if kb and steps_prof else None
     if headline and os.path.exists(pmc_path):
         allp = json.load(open(pmc_path))
-        steps_prof = float(allp.get("_steps", 0))
-        if steps_prof:
-            kb = 0.0   # all launches of the stage's kernels in the profiled run (bench.py --only-headline), per step
-            for k, v in allp.items():
-                if k.startswith(FILL_STAGE) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                    kb += 2.0 * v["FETCH_SIZE"]["total_kb"] + v["WRITE_SIZE"]["total_kb"]
-            traffic = round(kb * 1024.0 / steps_prof) if kb else None
+        traffic = pmc_bytes(allp, FILL_STAGE)       # all launches of the stage's kernels in the profiled run (bench.py --only-headline), per step
+        traffic_step = pmc_bytes(allp, STEP)        # ... with the prep and emission kernels in front of the stage
     pmc_all = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    pmc_sat_path = os.path.join(ROOT, "profiles/r4_satellites_pmc.json")   # the same passes over `bench.py --only-satellites`
+    if os.path.exists(pmc_sat_path):
+        for k, v in json.load(open(pmc_sat_path)).items():
+            if isinstance(v, dict) and k.startswith(("pgm_nw_kernel", "pgm_csprofile_kernel")):
+                pmc_all[k] = v
 
     def valu_roofline(kernel, launch_ms):
         """VALU issue rate of a compute-bound satellite kernel: SQ_INSTS_VALU of one launch (profiles/r2_pmc.json, rocprofv3
@@ -283,10 +308,12 @@ def main():
               "largest_job": {"rows_x_cols": "%d x %d" % (jobs[big].g1.n, jobs[big].g2.n), "sweeps": round(float(tk[big, 0] + off)), "traceback": round(float(tk[big, 1] + off))}}
     except Exception as e:   # (an older library without the entry point)
         tl = {"error": str(e)}
-    roofline = {"bound": "hbm", "kernel": "fill stage: pgm_fill_kernel (two launches: the longest chains, the other MODE 2 jobs), pgm_band_kernel and pgm_lean_kernel side by side, "
-                                          "an instance of pgm_tb_kernel (tracebacks) behind each of the first three", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "algorithmic_bytes": alg_bytes, "timeline_us": tl,
-                "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes over `bench.py --only-headline`; bytes per step = sum over the stage's kernel launches of 2 x FETCH_SIZE + WRITE_SIZE)",
+    roofline = {"bound": "hbm", "kernel": "fill stage: pgm_crit_kernel (two launches: the longest chains on sixteen wavefronts per band, the other jobs of 20 and more bands), "
+                                          "pgm_band_kernel (narrow and wide bands) and pgm_lean_kernel side by side, an instance of pgm_tb_kernel (tracebacks) behind each of the first three",
+                "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_whole_step": traffic_step, "algorithmic_bytes": alg_bytes, "timeline_us": tl,
+                "traffic_source": pmc_name + " (rocprofv3 --pmc, separate passes over `bench.py --only-headline`; bytes per step = sum over the stage's kernel launches of 2 x FETCH_SIZE + WRITE_SIZE; "
+                                             "traffic_whole_step: the same with pgm_prep_kernel and pgm_emission_skew_kernel, which write and re-read the emission scores)",
                 "ms": {"prep": round(ms_prep, 4), "emission": round(ms_emis, 4), "fill_and_traceback": round(ms_fill, 4),
                        "sum": round(ms_prep + ms_emis + ms_fill, 4), "source": "HIP events of the %d timed steps themselves (pgm_align_batch_stage_times)" % n_timed},
                 "fill_gcups": round(cells / (ms_fill * 1e-3) / 1e9, 3)}
@@ -299,7 +326,7 @@ def main():
     # ---- the two other lines SURVEY section 7 asks for: the leaf level alone, and the product's whole progressive pass --------
     def is_chain(g):
         return g.r_col is None and g.e_col.size == g.n - 1 and bool(np.all(g.e_col == np.arange(g.n - 1, dtype=np.uint32))) and bool(np.all(g.e_val != 0))
-    leaf_jobs = [j for j in jobs if is_chain(j.g1) and is_chain(j.g2)]
+    leaf_jobs = [] if args.only_satellites else [j for j in jobs if is_chain(j.g1) and is_chain(j.g2)]
     roofline_leaf = None
     if leaf_jobs:
         lb = J.Batch(ctx, leaf_jobs)
@@ -317,6 +344,10 @@ def main():
                          "ms": {"prep": round(lp, 4), "emission": round(le, 4), "fill_and_traceback": round(lf, 4)},
                          "gcups": round(lcells / (lf * 1e-3) / 1e9, 2), "achieved": round(16.0 * lcells / (lf * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(16.0 * lcells / (lf * 1e-3) / 8e12, 5),
+                         "binding": {"valu_issue": valu_roofline("pgm_lean_kernel", lf),
+                                     "hbm_bytes_per_launch_in_the_headline_batch": (pmc_bytes({k: v for k, v in pmc_all.items()}, ("pgm_lean_kernel",)) if pmc_all.get("_steps") else None),
+                                     "note": "the bound that binds this kernel is vector issue and the LDS hand-off between its wavefronts, not HBM: its VALU issue fraction, and the HBM bytes one "
+                                             "launch moves in the headline batch (profiles/r4_pmc.json) for comparison with the 16 B per cell of the notional figure"},
                          "note": "the chain-only jobs of the pass (sequence graph against sequence graph: the guide tree's leaf level) as a batch of their own; "
                                  "algorithmic bytes as for the headline (16 B per cell); these jobs keep 4 decision bits per cell instead of the four floats "
                                  "(DESIGN section 3.1), so the bytes actually moved are far fewer: S read 4 B + 0.5 B per cell"}
@@ -499,6 +530,10 @@ def main():
     configs = None
     if headline and rank == 0 and world == 1 and not args.no_extra:
         configs = {}
+
+        def cfg_traffic(name):   # HBM bytes per pass of the fill stage's kernels (profiles/r4_c4_pmc.json / r4_c5_pmc.json: passes over `bench.py --only-config`)
+            pth = os.path.join(ROOT, "profiles/r4_%s_pmc.json" % ("c4" if name.startswith("config4") else "c5"))
+            return pmc_bytes(json.load(open(pth)), FILL_STAGE) if os.path.exists(pth) else None
         lib_path = os.path.join(tmp, "K4000syn.lib")
         with open(lib_path, "w") as f:
             f.write(gen.genlib(4000, 11))
@@ -522,13 +557,18 @@ def main():
                              "gcups": round(b2.cells / d2 / 1e9, 3), "ms": {"prep": round(tm[0], 3), "emission": round(tm[1], 3), "fill_and_traceback": round(tm[2], 3)},
                              "fill_frac_of_hbm_roofline": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 4),
                              "roofline": {"bound": "hbm", "achieved": round(16.0 * b2.cells / (tm[2] * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                                          "frac": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 5), "traffic": None},
+                                          "frac": round(16.0 * b2.cells / (tm[2] * 1e-3) / 8e12, 5), "traffic": cfg_traffic(name)},
                              "pgmsa": {"wall_s": st["wall_s"], "init_s": st.get("init_s"), "progressive_s": st["progressive_s"], "align_call_s": st["align_s"]},
                              "fasta_identical_to_reference": md5 == md5s.get(ref_md5), "reference_one_pass_s": ref_s,
                              "note": "jobs of one progressive pass captured from the product driver, inputs resident in HBM; "
                                      "reference time: bin/ProGraphMSA_64 on one core of the build container"}
             b2.close()
 
+    if args.only_satellites:
+        if rank == 0:
+            print(json.dumps({"only_satellites": True, "all_pairs_nw": nw, "csprofile": cs}))
+        batch.close(); ctx.close()
+        return
     out = None
     if rank == 0:
         out = {
@@ -564,7 +604,8 @@ def main():
                 passes += 1
                 ccells += sum(j.cells for j in jobs)
             cdt = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": 1, "kind": "port",
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown")
+            out["cpu_baseline"] = {"value": round(ccells / cdt / 1e9, 5), "unit": "GCUPS", "cores": 1, "kind": "port", "host_cpu": cpu_model, "host_cores": os.cpu_count(),
                                    "sample": "%d pass(es) over the same %d-job batch (%.3e cells, %.1f s), oracle/pgm_oracle.c -O2, 1 thread"
                                              % (passes, len(jobs), ccells, cdt)}
         print(json.dumps(out))

@@ -51,9 +51,16 @@ __device__ __forceinline__ float pgm_emission_finish(float num, float ay, float 
 // coalesced and converted into LDS; every thread then works on its node from LDS (padded stride: conflict free), and the
 // results go back through LDS so that the stores are coalesced too.  The sums keep the reference's sequential order (one
 // multiply and one add per term, no FMA).  DMAX = 20 for amino acids (NODES = 256), 64 for codons (NODES = 64).
+// The kernel also zeroes the batch's sync block (progress words, tickets, abort flag) for the fill stage two kernels later: a
+// hipMemsetAsync between the emission kernel and the sweeps cost 55 us of fill kernel plus its dependency per step.
 template <int DMAX, int NODES>
-__global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restrict__ jobs) {
+__global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restrict__ jobs, int *__restrict__ sync, uint32_t sync_ints) {
     extern __shared__ float prep_lds[];  // Mf (dim*dim), pif (dim), nodes [NODES][dim+1]
+    {
+        const uint32_t nthreads = gridDim.x * gridDim.y * gridDim.z * NODES;
+        const uint32_t gid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NODES + threadIdx.x;
+        for (uint32_t i = gid; i < sync_ints; i += nthreads) sync[i] = 0;
+    }
     const PgmJob &J = jobs[blockIdx.x];
     const bool first = blockIdx.y == 0;
     const uint32_t n = first ? J.n1 : J.n2;

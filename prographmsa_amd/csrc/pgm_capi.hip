@@ -639,10 +639,10 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (timed && (e = hipEventRecord(b->ev[0], s)) != hipSuccess) return e;
     if (b->maxdim <= 20) {
         const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim + 256 * ((size_t)b->maxdim + 1)) * sizeof(float);
-        hipLaunchKernelGGL((pgm_prep_kernel<20, 256>), dim3(b->njobs, 2, (b->maxn + 255) / 256), dim3(256), prep_lds, s, b->d_jobs);
+        hipLaunchKernelGGL((pgm_prep_kernel<20, 256>), dim3(b->njobs, 2, (b->maxn + 255) / 256), dim3(256), prep_lds, s, b->d_jobs, b->d_sync, (uint32_t)b->sync_ints);
     } else {
         const size_t prep_lds = ((size_t)b->maxdim * b->maxdim + b->maxdim + 64 * ((size_t)b->maxdim + 1)) * sizeof(float);
-        hipLaunchKernelGGL((pgm_prep_kernel<64, 64>), dim3(b->njobs, 2, (b->maxn + 63) / 64), dim3(64), prep_lds, s, b->d_jobs);
+        hipLaunchKernelGGL((pgm_prep_kernel<64, 64>), dim3(b->njobs, 2, (b->maxn + 63) / 64), dim3(64), prep_lds, s, b->d_jobs, b->d_sync, (uint32_t)b->sync_ints);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed && (e = hipEventRecord(b->ev[1], s)) != hipSuccess) return e;
@@ -651,7 +651,6 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (b->maxdim <= 20) hipLaunchKernelGGL((pgm_emission_skew_kernel<20, 1>), eg, dim3(4 * PGM_ROWS), 0, s, b->d_jobs);
     else hipLaunchKernelGGL((pgm_emission_skew_kernel<64, 1>), eg, dim3(4 * PGM_ROWS), 0, s, b->d_jobs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b->d_sync, 0, b->sync_ints * sizeof(int), s)) != hipSuccess) return e;  // progress counters + abort flag
     if (timed && (e = hipEventRecord(b->ev[2], s)) != hipSuccess) return e;
     // One kernel does the DP fill of every band and, right after a job's last band, that job's traceback.
     const char *dbg = tools_env("PGM_FILL_DBG");   // 8: the fill alone, no traceback (tools build)

@@ -34,7 +34,7 @@ print(json.dumps(summary, indent=1, sort_keys=True))
 # trace), next to each kernel's own mean duration -> <tag>_stage_span.json; bench.py's roofline.ms.fill_and_traceback is this span.
 trace = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getsize)
 if trace:
-    STAGE = ("pgm_fill_kernel", "pgm_band_kernel", "pgm_lean_kernel", "pgm_tb_kernel")
+    STAGE = ("pgm_fill_kernel", "pgm_crit_kernel", "pgm_band_kernel", "pgm_lean_kernel", "pgm_tb_kernel")
     rows = [r for r in csv.DictReader(open(trace[-1])) if "pgm_" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     steps, cur = [], None
