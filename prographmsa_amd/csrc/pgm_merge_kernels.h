@@ -90,10 +90,10 @@ __global__ void __launch_bounds__(256) pgm_onehot_kernel(uint32_t dim, uint32_t 
     const uint32_t s = lo, L = offs[s + 1] - offs[s];
     const uint64_t k = c - col0[s];
     double *dst = out + c * dim;
-    int sym = -2;   // START / END
-    if (k >= 1 && k <= L) sym = syms[offs[s] + (uint32_t)(k - 1)];
+    const bool residue = k >= 1 && k <= L;   // (else START / END: a zero column — not a symbol value: every negative int8 means "no value")
+    const int sym = residue ? (int)syms[offs[s] + (uint32_t)(k - 1)] : 0;
     const double uni = 1.0 / (double)dim;
-    for (uint32_t r = 0; r < dim; ++r) dst[r] = sym == -2 ? 0.0 : (sym < 0 ? uni : ((uint32_t)sym == r ? 1.0 : 0.0));
+    for (uint32_t r = 0; r < dim; ++r) dst[r] = !residue ? 0.0 : (sym < 0 ? uni : ((uint32_t)sym == r ? 1.0 : 0.0));
 }
 
 #endif

@@ -162,3 +162,45 @@ def test_resident_profiles_through_merge_and_alignment(ctx):
     got = cj.results()[0]
     assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
     assert np.array_equal(got["map1"], ref["map1"]) and np.array_equal(got["map2"], ref["map2"])
+
+
+def test_resident_onehot_leaves_against_the_oracle(ctx):
+    """pgm_resident_onehot (the leaf graphs of a pass built in HBM: reference src/SequenceGraph.h:101-109) checked at unit level
+    against the ORACLE: two sequence graphs whose profile columns exist only on the device — one-hot for a residue with a value,
+    uniform 1 / dim for one without (negative symbol), zero START / END columns — aligned through pgm_site_ref give the oracle's
+    score and mappings for the same graphs with the columns written out on the host."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    import oracle_lib
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for D in (20, 61):
+        rng = np.random.default_rng(900 + D)
+        lens = [73, 131]
+        syms = [rng.integers(0, D, L).astype(np.int8) for L in lens]
+        for s in syms:
+            s[rng.random(len(s)) < 0.08] = -1          # residues without a value: uniform columns
+        syms[0][5] = -2                                 # any negative symbol is "no value"
+        flat = np.concatenate(syms).astype(np.int8)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        dev = (C.POINTER(C.c_double) * 2)()
+        pg.check(pg.lib.pgm_resident_reset(ctx.handle))
+        pg.check(pg.lib.pgm_resident_onehot(ctx.handle, D, 2, P(flat, C.c_int8), P(offs, C.c_uint32), dev))
+        # the same columns on the host, as the reference's SequenceGraph lays them out (node-major: n x dim)
+        def columns(s):
+            m = np.zeros((len(s) + 2, D))
+            for i, v in enumerate(s):
+                if v >= 0: m[i + 1, v] = 1.0
+                else: m[i + 1, :] = 1.0 / D
+            return m
+        job = J.random_job(4242 + D, lens[0] + 2, lens[1] + 2, dim=D, skip_frac=0.0, drop_chain_frac=0.0)
+        job.g1.sites = columns(syms[0]).reshape(-1)
+        job.g2.sites = columns(syms[1]).reshape(-1)
+        ref = oracle_lib.align_graphs(job)
+        cj = J.CJobs([job])
+        r1 = (pg.pgm_site_ref * 1)(); r2 = (pg.pgm_site_ref * 1)()
+        r1[0].dev_sites, r1[0].node_map, r1[0].ncols = dev[0], None, lens[0] + 2
+        r2[0].dev_sites, r2[0].node_map, r2[0].ncols = dev[1], None, lens[1] + 2
+        pg.check(pg.lib.pgm_align_graphs_batch_res(ctx.handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out))
+        got = cj.results()[0]
+        assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
+        assert np.array_equal(got["map1"], ref["map1"]) and np.array_equal(got["map2"], ref["map2"])
