@@ -1,6 +1,6 @@
 """Randomised parity campaign (GPU box): batches of random jobs — random sizes, edge densities, edge lengths, repeat edges,
 dropped chain edges, alphabet sizes — through the HIP path and the oracle; scores, mappings, n_tr_indels and (for a sample)
-the four DP matrices must be bit-identical.  usage: tools/fuzz_align.py SECONDS [SEED]"""
+the four DP matrices must be bit-identical.  usage: tools/fuzz_align.py SECONDS [SEED]   (FUZZ_CRIT=1: biased towards pgm_crit_kernel / wide bands)"""
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -25,6 +25,10 @@ while time.time() < t_end:
               onehot_frac=float(rng.choice([0.0, 0.5, 1.0])))
     dim = int(rng.choice([20, 20, 20, 61, 4]))
     big = rng.random() < 0.15
+    if os.environ.get("FUZZ_CRIT"):   # bias towards the jobs of pgm_crit_kernel and of the wide band workers: many bands or a 32-step history, no long edges, no dropped chain edges
+        kw.update(skip_span=int(rng.choice([2, 3, 9, 14, 20, 27])), skip_max=int(rng.choice([1, 2, 3, 5])), drop_chain_frac=0.0,
+                  skip_frac=float(rng.choice([0.02, 0.05, 0.2, 0.5])), repeat_span=int(rng.choice([10, 20])))
+        big = rng.random() < 0.6
     sizes = [(int(rng.integers(2, 2600 if big else 700)), int(rng.integers(2, 2600 if big else 700))) for _ in range(3 if big else int(rng.integers(1, 24)))]
     js = [J.random_job(int(rng.integers(1 << 30)), n1, n2, dim=dim, **kw) for n1, n2 in sizes]
     b = J.Batch(ctx, js, keep_matrices=True)
