@@ -981,8 +981,8 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                         const uint32_t nn = side ? g2[i]->n : g1[i]->n;
                         for (uint32_t v = 0; v < nn; ++v) { gen[side] += (ni[v].flags & PGM_NF_GENERIC) != 0; if (side) lng += PGM_NF_NLONG(ni[v].flags); }
                     }
-                    fprintf(stderr, "pgm job %u: %u x %u mode2 %u hD %u hDX %u far_slack %u generic rows %u cols %u remote row entries %u long col entries %u far nodes %u + %u overflow cols %u\n",
-                            i, g1[i]->n, g2[i]->n, J.mode2, J.hD, J.hDX, J.far_slack, gen[0], gen[1], o.s1.remote, lng, o.s1.far_nodes, o.s2.far_nodes, J.nov2);
+                    fprintf(stderr, "pgm job %u: %u x %u mode2 %u crit3 %u slot %u B hD %u hDX %u far_slack %u generic rows %u cols %u remote row entries %u long col entries %u far nodes %u + %u overflow cols %u\n",
+                            i, g1[i]->n, g2[i]->n, J.mode2, J.crit3, J.slot_bytes, J.hD, J.hDX, J.far_slack, gen[0], gen[1], o.s1.remote, lng, o.s1.far_nodes, o.s2.far_nodes, J.nov2);
                     for (int side = 0; side < 2; ++side) {
                         const SideOff &so = side ? o.s2 : o.s1;
                         const PgmNode2 *ni = (const PgmNode2 *)(b->h_in + so.ni);

@@ -91,6 +91,49 @@ def test_large_heavy_tailed_jobs_bit_exact(ctx):
     b.close()
 
 
+def test_critical_path_kernel_and_wide_bands_bit_exact(ctx):
+    """Jobs of pgm_crit_kernel (20 and more bands, every predecessor near or within the on-chip history: the chain terms on one wavefront,
+    everything else on fifteen others) and of pgm_band_kernel's wide workers (a 32-step history, fewer than 20 bands), 20 and 61 states:
+    all four DP matrices, scores and mappings against the oracle; in one batch, so that workers take several bands one after another."""
+    from prographmsa_amd import jobs as J
+    for dim in (20, 61):
+        js = [J.random_job(7100 + dim, 1500, 1400, dim=dim, skip_frac=0.25, skip_span=27, skip_max=2, drop_chain_frac=0.0),   # remote rows: the helper sweep of the fill kernel
+              J.random_job(7200 + dim, 1300, 700, dim=dim, skip_frac=0.1, skip_span=9, skip_max=3, drop_chain_frac=0.0),    # near and a few far edges, 21 bands: pgm_crit_kernel
+              J.random_job(7300 + dim, 1000, 1100, dim=dim, skip_frac=0.2, skip_span=20, skip_max=2, drop_chain_frac=0.0),
+              J.random_job(7400 + dim, 1290, 90, dim=dim, skip_frac=0.5, skip_span=5, skip_max=3, drop_chain_frac=0.0),     # short columns: the sweep is mostly ramp (pgm_crit_kernel)
+              J.random_job(7500 + dim, 400, 380, dim=dim, skip_frac=0.2),                                                   # (pgm_crit_kernel)
+              # few far edges, a 32-step history, chains well below the longest job's: the wide workers of pgm_band_kernel
+              J.random_job(7600 + dim, 450, 400, dim=dim, skip_frac=0.03, skip_span=9, skip_max=2, drop_chain_frac=0.0),
+              J.random_job(7700 + dim, 600, 300, dim=dim, skip_frac=0.02, skip_span=12, skip_max=2, drop_chain_frac=0.0),
+              J.random_job(7800 + dim, 300, 500, dim=dim, skip_frac=0.04, skip_span=10, skip_max=3, drop_chain_frac=0.0)]
+        b = J.Batch(ctx, js, keep_matrices=True)
+        b.run()
+        res = b.fetch()
+        for i, j in enumerate(js):
+            _cmp_job(b, i, j, res[i])
+        b.close()
+
+
+def test_handoff_timeout_in_the_critical_path_kernel(ctx):
+    """The same time-out path as below for a job swept by pgm_crit_kernel: band 3 never publishes its progress, the chain wavefront of band 4
+    gives up, raises the abort flag, every wavefront of every worker leaves, the batch reports PGM_ERR_DEVICE — and runs clean afterwards."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    import oracle_lib
+    js = [J.random_job(7600, 1400, 600, skip_frac=0.2, skip_span=20, skip_max=2, drop_chain_frac=0.0)]
+    b = J.Batch(ctx, js)
+    pg.check(pg.lib.pgm_align_batch_test_stall(b.handle, 0, 3, 2000))
+    b.run()
+    rc = pg.lib.pgm_align_batch_fetch(ctx.handle, b.handle, b.cj.out)
+    assert rc == pg.PGM_ERR_DEVICE and b"timed out" in pg.lib.pgm_last_error()
+    pg.check(pg.lib.pgm_align_batch_test_stall(b.handle, 0xFFFFFFFF, 0, 0))
+    b.run()
+    res = b.fetch()
+    ref = oracle_lib.align_graphs(js[0])
+    assert res[0]["status"] == 0 and np.array_equal(res[0]["map1"], ref["map1"]) and np.array_equal(res[0]["map2"], ref["map2"])
+    b.close()
+
+
 def test_relaunch_and_fetch(ctx):
     """run, run, fetch and run, fetch, fetch: the result records in the pinned block are reset by every launch and copied
     out by fetch while the kernel is still running (status word last); every fetch returns the same results."""
