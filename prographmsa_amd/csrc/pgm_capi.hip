@@ -1461,6 +1461,13 @@ int pgm_align_batch_fetch(pgm_ctx *ctx, pgm_align_batch *b, pgm_align_out *out) 
             for (double &v : acc) v /= n * 100.0;
             fprintf(stderr, "c3dbg job %u (%u x %u, %u bands, %u steps): chain %.0f us, of it waiting for fold %.0f, for the band above %.0f (%.0f waits per band) | fold 0: %.0f us, waiting for the record %.0f, for helpers %.0f (%.0f late) | fold 1: %.0f / %.0f / %.0f (%.0f) | near: %.0f us waiting %.0f; %.0f / %.0f\n",
                     j, b->jobs[j].n1, b->jobs[j].n2, b->jobs[j].nb, b->jobs[j].tsteps, acc[0], acc[1], acc[2], acc[3] * 100.0, acc[4], acc[5], acc[6], acc[7] * 100.0, acc[8], acc[9], acc[10], acc[11] * 100.0, acc[12], acc[13], acc[16], acc[17]);
+            if (want) for (uint32_t k = 0; k < b->nitems; ++k) if (its[k].job == j && (its[k].band % 4u == 0u || its[k].band + 1u == b->jobs[j].nb)) {   // every fourth band of the job asked for
+                const unsigned long long *g = dg.data() + 64 * (size_t)k;
+                fprintf(stderr, "   band %2u: chain %.0f us (waiting for fold %.0f, for the band above %.0f), %.2f GHz | fold 0 waits: record %.0f, helpers %.0f | near waits %.0f | helpers poll/all: cols", its[k].band, g[0] / 100.0, g[1] / 100.0, g[2] / 100.0,
+                        (double)g[60] / std::max<double>(1.0, (double)g[0]) / 10.0, g[5] / 100.0, g[6] / 100.0, g[13] / 100.0);
+                for (int q = 0; q < 10; ++q) { const int w = q < 8 ? 20 + q : 28 + q; fprintf(stderr, "%s %.0f/%.0f", q == 4 ? " rows" : "", g[w] / 100.0, g[w + 8] / 100.0); }
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "   helpers (poll us / all us): columns");
             for (int k = 0; k < 10; ++k) { const int w = k < 8 ? 20 + k : 28 + k; fprintf(stderr, "%s %.0f/%.0f", k == 4 ? " | rows" : "", acc[w], acc[w + 8]); }
             fprintf(stderr, "\n");

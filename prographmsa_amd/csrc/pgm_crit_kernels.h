@@ -49,7 +49,7 @@ template <bool DBG>
 __device__ __forceinline__ void pgm_crit_sweep(const PgmJob &J, const uint32_t b, uint8_t *slot, const int lane, int *abort_flag, bool &aborted,
                                                const uint32_t spin_limit, const bool stall, int *sw_generic, unsigned long long *dbg) {
     unsigned long long d_fold = 0, d_prev = 0, d_n = 0;
-    const unsigned long long d_t0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long d_t0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull, d_c0 = DBG ? __builtin_readcyclecounter() : 0ull;
     constexpr int BL = PGM_BLOCK, VL = PGM_VL, HS = 64 + PGM_VL, NR = PGM_NRING, RS = 5;
     typedef __attribute__((address_space(3))) int pgm_lds_int;
     typedef float pgm_v2f __attribute__((ext_vector_type(2)));
@@ -258,7 +258,7 @@ __device__ __forceinline__ void pgm_crit_sweep(const PgmJob &J, const uint32_t b
         poll_issue();
     }
     __hip_atomic_store(sw, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the other wavefronts (also after an abort)
-    if (DBG && dbg && lane == 0) { dbg[0] = __builtin_amdgcn_s_memrealtime() - d_t0; dbg[1] = d_fold; dbg[2] = d_prev; dbg[3] = d_n; }
+    if (DBG && dbg && lane == 0) { dbg[0] = __builtin_amdgcn_s_memrealtime() - d_t0; dbg[1] = d_fold; dbg[2] = d_prev; dbg[3] = d_n; dbg[60] = __builtin_readcyclecounter() - d_c0; }   // ([60]: shader cycles of the band)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && !stall) __hip_atomic_store(&J.prog[b], aborted ? (int)0 : (int)0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

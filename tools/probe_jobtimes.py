@@ -13,8 +13,9 @@ fam, flags = {"c3": (lambda: gen.gen(256, 1000, 3), ["--fasta", "-m", "-t", os.p
               "c4": (lambda: gen.gen_codon(128, 1000, 4), ["--codon", "--fasta", "-t", os.path.join(ROOT, "tests/golden/c4.tree")]),
               "c5": (lambda: gen.gen(1024, 600, 6), ["--fasta", "-t", os.path.join(ROOT, "tests/golden/c5.tree")])}[cfg]
 fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam()))
-dump = os.path.join(tmp, "jobs.bin")
-subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True, env=dict(os.environ, PGM_HOST_PROFILE="1" if os.environ.get("PROBE_LISTS") else "0"))
+dump = os.environ.get("PROBE_DUMP", os.path.join(tmp, "jobs.bin"))   # (PROBE_DUMP: made once, by a library whose results are valid — ab_jobtimes.sh)
+if not os.path.exists(dump):
+    subprocess.run([pg.PGMSA_PATH] + flags + ["--dump_jobs", dump, "-o", os.path.join(tmp, "o.fa"), fa], check=True, env=dict(os.environ, PGM_HOST_PROFILE="1" if os.environ.get("PROBE_LISTS") else "0"))
 jobs = J.load_jobs(dump)
 if os.environ.get("PROBE_TOP"):    # the largest jobs alone (7: the MODE 2 jobs; 127: everything but the leaf level)
     jobs = sorted(jobs, key=lambda j: -j.cells)[:int(os.environ["PROBE_TOP"])]
@@ -23,7 +24,7 @@ if os.environ.get("PROBE_SET"):    # the root with one kind of company: "lean" (
     jobs = srt[:1] + {"lean": srt[127:], "mid": srt[7:127], "big": srt[1:7], "midlean": srt[7:]}[os.environ["PROBE_SET"]]
 ctx = pg.Context(0)
 b = J.Batch(ctx, jobs)
-for rep in range(2):
+for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
     b.run(); b.fetch_raw()
     ms = b.stage_times()
     t = np.zeros(2 * len(jobs), np.uint64)
@@ -41,3 +42,6 @@ for rep in range(2):
             print("  %-26s %3d jobs: last sweep ends %5.0f us (median %5.0f), last traceback published %5.0f us (median %5.0f)" % (name, m.sum(), sw[m].max(), np.median(sw[m]), dn[m].max(), np.median(dn[m])))
     for i in np.argsort(-dn)[:6]:
         print("    job %3d (%d x %d): sweeps end %5.0f us, published %5.0f us" % (i, jobs[i].g1.n, jobs[i].g2.n, sw[i], dn[i]))
+    if os.environ.get("PROBE_ALL"):   # every job that is not chain-only, largest first
+        for i in sorted(np.nonzero(~chain)[0], key=lambda i: -jobs[i].cells):
+            print("    job %3d (%d x %d): sweeps end %5.0f us, published %5.0f us" % (i, jobs[i].g1.n, jobs[i].g2.n, sw[i], dn[i]))
