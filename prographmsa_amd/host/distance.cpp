@@ -291,9 +291,14 @@ static double support(double d) {
 // accumulators added, an odd last packet added, the two lanes added, then the unaligned head and the tail element.
 // It matters: when four clusters are left the criterion has the exact tie Q(0,1) = Q(2,3), and the last bit of these sums
 // decides which pair is joined, i.e. where the guide tree is rooted (tests/golden: c1.nw_ml.tree, t9.nw_p.tree, t13.nw_p.tree).
-static double eigen_column_sum(DistanceMatrix &dist, int j) {
-    const int n = dist.dim;
-    auto at = [&](int i) { return dist.D(i, j); };   // the matrix is symmetric
+// The matrix is not rebuilt after a join (the reference's reduce() copies dim^2 doubles twice per join): it stays in its
+// n0 x n0 storage and `act` lists the rows / columns still in it, in the order of the reduced matrix.  The matrix need not be
+// symmetric in its last bits (the k-mer angle distances are not, see angleDistances) and BioNJ reads it by rows, by columns and
+// at (index1, index2) as well as (index2, index1): a transposed copy keeps the column reads of the sums and of the criterion
+// on contiguous memory.
+static double eigen_column_sum(const std::vector<double> &tr, size_t ld, const std::vector<int> &act, int n, int j) {
+    const double *col = &tr[(size_t)act[(size_t)j] * ld];   // column act[j] of the distances: a row of their transpose
+    auto at = [&](int i) { return col[(size_t)act[(size_t)i]]; };
     const int start = std::min<int>(((size_t)j * n) & 1, n);
     const int end2 = start + ((n - start) / 4) * 4, end = start + ((n - start) / 2) * 2;
     if (end == start) {
@@ -314,49 +319,90 @@ static double eigen_column_sum(DistanceMatrix &dist, int j) {
     return res;
 }
 
+// O(N^2) per join, N - 3 joins.  What the reference does per join — clamp every entry, column sums, the scan of the criterion, a
+// copy of the matrix without the joined column — is here: the clamp of the entries the previous join wrote (the others were
+// clamped when they were written, and nothing reads an entry between its join and the next clamp), sums and scan on the host
+// threads from 512 clusters on (ranges of columns; the scan keeps the FIRST minimum in column-major order like Eigen's
+// minCoeff: a range keeps its first, the ranges are combined in order with the same strict comparison), and no copy.
 PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
     const double MIN_DIST = 1e-4, MIN_VAR = 1e-5;
+    const int n0 = (int)seqs_order.size();
     std::vector<PhyTree *> subtrees;
     for (const std::string &s : seqs_order) subtrees.push_back(new PhyTree(s));
-    for (int dim = (int)seqs_order.size(); dim > 3; --dim) {
-        for (double &d : dist.distances) d = std::max(d, MIN_DIST);
-        for (double &v : dist.variances) v = std::max(v, MIN_VAR);
-        for (int i = 0; i < dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
-        std::vector<double> sums(dim, 0.0);  // colwise sums
-        for (int j = 0; j < dim; ++j) sums[j] = eigen_column_sum(dist, j);
+    std::vector<int> act((size_t)n0);
+    for (int i = 0; i < n0; ++i) act[(size_t)i] = i;
+    auto D = [&](int i, int j) -> double & { return dist.D(act[(size_t)i], act[(size_t)j]); };   // (reduced indices)
+    auto V = [&](int i, int j) -> double & { return dist.V(act[(size_t)i], act[(size_t)j]); };
+    int fresh = -1;   // reduced index of the row / column the previous join wrote (not clamped yet); -1: the whole matrix is new
+    std::vector<double> sums;
+    const size_t ld = (size_t)n0;
+    std::vector<double> tr((size_t)n0 * n0);   // tr[j ld + i] = dist.D(i, j)
+    auto T = [&](int i, int j) -> double & { return tr[(size_t)act[(size_t)j] * ld + (size_t)act[(size_t)i]]; };   // the same element as D(i, j)
+    for (int dim = n0; dim > 3; --dim) {
+        if (fresh < 0) {
+            for (double &d : dist.distances) d = std::max(d, MIN_DIST);
+            for (double &v : dist.variances) v = std::max(v, MIN_VAR);
+            for (int i = 0; i < dim; ++i) { D(i, i) = 0; V(i, i) = 0; }
+            for (int i = 0; i < n0; ++i)
+                for (int j = 0; j < n0; ++j) tr[(size_t)j * ld + (size_t)i] = dist.distances[(size_t)i * ld + (size_t)j];
+        } else {
+            for (int i = 0; i < dim; ++i) {   // (the entries a join writes are symmetric)
+                if (i == fresh) continue;
+                D(fresh, i) = D(i, fresh) = T(fresh, i) = T(i, fresh) = std::max(D(i, fresh), MIN_DIST);
+                V(fresh, i) = V(i, fresh) = std::max(V(i, fresh), MIN_VAR);
+            }
+        }
+        sums.assign((size_t)dim, 0.0);  // colwise sums
+        const bool threads = dim >= 512;   // (a section of half a millisecond and more; tests/test_oracle_golden.py: the 1024-taxon tree)
+        const size_t nranges = threads ? 16 : 1;
+        auto range = [&](size_t r, int &c0, int &c1) { c0 = (int)((size_t)dim * r / nranges); c1 = (int)((size_t)dim * (r + 1) / nranges); };
+        auto sum_range = [&](size_t r) { int c0, c1; range(r, c0, c1); for (int j = c0; j < c1; ++j) sums[(size_t)j] = eigen_column_sum(tr, ld, act, dim, j); };
+        if (threads) parallel_for(nranges, sum_range); else sum_range(0);
         // Q = 0.5 d - 0.5/(dim-2) (S + S^T); minCoeff scans column-major (row index fastest) and keeps the first minimum
+        struct Best { double min; int row, col; };
+        std::vector<Best> best(nranges, Best{INFINITY, 0, 0});
+        auto scan_range = [&](size_t r) {
+            int c0, c1; range(r, c0, c1);
+            Best bq{INFINITY, 0, 0};
+            const double f = 0.5 / (dim - 2.0);
+            for (int col = c0; col < c1; ++col) {
+                const double *colp = &tr[(size_t)act[(size_t)col] * ld];   // column col of the distances
+                const double sc = sums[(size_t)col];
+                for (int row = 0; row < dim; ++row) {
+                    if (row == col) continue;
+                    const double q = 0.5 * colp[(size_t)act[(size_t)row]] - f * (sc + sums[(size_t)row]);
+                    if (q < bq.min) { bq.min = q; bq.row = row; bq.col = col; }
+                }
+            }
+            best[r] = bq;
+        };
+        if (threads) parallel_for(nranges, scan_range); else scan_range(0);
         int index1 = 0, index2 = 0;
         double min = INFINITY;
-        for (int col = 0; col < dim; ++col)
-            for (int row = 0; row < dim; ++row) {
-                if (row == col) continue;
-                double q = 0.5 * dist.D(row, col) - (0.5 / (dim - 2.0)) * (sums[col] + sums[row]);
-                if (q < min) { min = q; index2 = row; index1 = col; }
-            }
+        for (size_t r = 0; r < nranges; ++r) if (best[r].min < min) { min = best[r].min; index2 = best[r].row; index1 = best[r].col; }
         if (index2 < index1) std::swap(index1, index2);
         std::string name1 = seqs_order[index1], name2 = seqs_order[index2];
-        double dist1 = (dist.D(index1, index2) + (sums[index1] - sums[index2]) / (dim - 2.0)) / 2.0;
-        dist1 = std::min(std::max(dist1, MIN_DIST), dist.D(index1, index2));
-        double dist2 = std::max(dist.D(index2, index1) - dist1, MIN_DIST);
+        double dist1 = (D(index1, index2) + (sums[index1] - sums[index2]) / (dim - 2.0)) / 2.0;
+        dist1 = std::min(std::max(dist1, MIN_DIST), D(index1, index2));
+        double dist2 = std::max(D(index2, index1) - dist1, MIN_DIST);
         double vsum = 0;
-        for (int i = 0; i < dim; ++i) vsum += dist.V(index2, i) - dist.V(index1, i);
-        double lambda = .5 + vsum / (2 * (dim - 2) * dist.V(index1, index2));
+        for (int i = 0; i < dim; ++i) vsum += V(index2, i) - V(index1, i);
+        double lambda = .5 + vsum / (2 * (dim - 2) * V(index1, index2));
         if (std::isnan(lambda)) lambda = .5;
         else lambda = std::min(std::max(0.0, lambda), 1.0);
 
-        DistanceMatrix red(dim - 1);
-        auto old = [&](int i) { return i < index2 ? i : i + 1; };  // reduce(index2)
-        for (int i = 0; i < dim - 1; ++i)
-            for (int j = 0; j < dim - 1; ++j) { red.D(i, j) = dist.D(old(i), old(j)); red.V(i, j) = dist.V(old(i), old(j)); }
-        for (int i = 0; i < dim - 1; ++i) {
-            int o = old(i);
-            double nd = lambda * (dist.D(index1, o) - dist1) + (1.0 - lambda) * (dist.D(index2, o) - dist2);
-            double nv = lambda * dist.V(index1, o) + (1.0 - lambda) * dist.V(index2, o) - lambda * (1.0 - lambda) * dist.V(index1, index2);
+        // reduce(index2) + the joined cluster in row / column index1 (TreeNJ.cpp:230-262)
+        const double v12 = V(index1, index2);
+        for (int i = 0; i < dim; ++i) {
+            if (i == index2) continue;
+            double nd = lambda * (D(index1, i) - dist1) + (1.0 - lambda) * (D(index2, i) - dist2);
+            double nv = lambda * V(index1, i) + (1.0 - lambda) * V(index2, i) - lambda * (1.0 - lambda) * v12;
             if (i == index1) { nd = 0; nv = 0; }
-            red.D(index1, i) = red.D(i, index1) = nd;
-            red.V(index1, i) = red.V(i, index1) = nv;
+            D(index1, i) = D(i, index1) = T(index1, i) = T(i, index1) = nd;
+            V(index1, i) = V(i, index1) = nv;
         }
-        dist = red;
+        act.erase(act.begin() + index2);
+        fresh = index1;   // (index1 < index2: its reduced index stays)
         seqs_order.erase(seqs_order.begin() + index2);
         seqs_order[index1] = name1 + "," + name2;
         PhyTree *tree = new PhyTree(seqs_order[index1]);
@@ -367,14 +413,14 @@ PhyTree *buildNJTree(std::vector<std::string> seqs_order, DistanceMatrix dist) {
     }
     PhyTree *tree = new PhyTree("root");
     if (seqs_order.size() == 2) {
-        double d = dist.D(0, 1) / 2;
+        double d = D(0, 1) / 2;
         tree->addChild(subtrees[0], d, support(d));
         tree->addChild(subtrees[1], d, support(d));
     } else {
-        double d0 = (dist.D(0, 1) + dist.D(0, 2) - dist.D(1, 2)) / 2.0;
-        d0 = std::min(std::max(d0, MIN_DIST), std::min(dist.D(1, 0), dist.D(2, 0)));
-        double d1 = std::max(dist.D(1, 0) - d0, MIN_DIST);
-        double d2 = std::max(dist.D(2, 0) - d0, MIN_DIST);
+        double d0 = (D(0, 1) + D(0, 2) - D(1, 2)) / 2.0;
+        d0 = std::min(std::max(d0, MIN_DIST), std::min(D(1, 0), D(2, 0)));
+        double d1 = std::max(D(1, 0) - d0, MIN_DIST);
+        double d2 = std::max(D(2, 0) - d0, MIN_DIST);
         PhyTree *tree2 = new PhyTree("root2");
         tree2->addChild(subtrees[0], d0, support(d0));
         tree2->addChild(subtrees[1], d1, support(d1));
@@ -497,10 +543,15 @@ DistanceMatrix angleDistances(const Alphabet &a, const std::map<std::string, seq
     Backend &be = default_backend();
     const auto t0 = std::chrono::steady_clock::now();
     be.kmer_cosine(n, ncols, counts.data(), distances.distances.data());   // :100
+    // kmer_cosine writes element (i, j) at i + n j (the reference's column-major matrix); DistanceMatrix::D(i, j) reads i n + j.  The
+    // matrix is NOT symmetric in its last bits — ((c_i / |c_i|) . c_j) / |c_j| is rounded differently from the (j, i) element — and
+    // BioNJ reads it by rows, by columns and at (index1, index2) / (index2, index1): the orientation has to be the reference's.
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = i + 1; j < n; ++j) std::swap(distances.distances[(size_t)i * n + j], distances.distances[(size_t)j * n + i]);
     be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const bool ml = cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag;
     for (double &d : distances.distances) {   // :101-105
-        d = -1.0 * std::log((d * d + 0.4) / 1.4);
+        d = -1.0 * std::log((d * d + 0.4) * (1.0 / 1.4));   // (Eigen 3.1: array / scalar multiplies by the reciprocal)
         if (!ml) {
             const double e = std::exp(d);
             d = -0.5 * (5.0 * e - std::sqrt(45.0 * (e * e) - 20.0 * e)) * (1.0 / e);
