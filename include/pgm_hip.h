@@ -245,7 +245,9 @@ int pgm_prealigned_counts_batch(pgm_ctx *ctx, uint32_t dim, uint32_t nrows, uint
 /* ---- (f4) DistanceFactoryAngle's cosine matrix — replaces the dense product of reference src/DistanceFactoryAngle.h:100
  * (`norms^-1 * counts2^T * counts2 * norms^-1`, the default initial distances without -a).  counts: nseq x ncols int32,
  * row-major (row i = the K-mer counts of sequence i; ncols = DIM^K).  cosine: nseq x nseq doubles, column-major,
- * cosine(i, j) = (sum_k (c_ik / |c_i|) c_jk) / |c_j| with k ascending (fp64, one multiply and one add per term). */
+ * cosine(i, j) = (sum_k (c_ik / |c_i|) c_jk) / |c_j| with k ascending (fp64, one multiply and one add per term), summed in the
+ * depth blocks of the reference's GEMM — L1d / 128 terms each, L1d = 49152 bytes unless the environment names the size the
+ * reference's host reports (PGM_EIGEN_L1D).  The matrix is NOT symmetric in its last bits; element (i, j) is at i + nseq j. */
 int pgm_kmer_cosine(pgm_ctx *ctx, uint32_t nseq, uint32_t ncols, const int32_t *counts, double *cosine);
 /* Device time of the kernel of the last pgm_mldist_batch / pgm_prealigned_counts_batch / pgm_kmer_cosine call on this context (ms). */
 float pgm_dist_last_kernel_ms(pgm_ctx *ctx);

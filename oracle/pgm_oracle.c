@@ -822,11 +822,23 @@ int pgmo_kmer_cosine(uint32_t nseq, uint32_t ncols, const int32_t *counts, doubl
         for (uint32_t k = 0; k < ncols; ++k) { const long long c = counts[(size_t)i * ncols + k]; ss += (unsigned long long)(c * c); }
         inv[i] = 1.0 / sqrt((double)ss);
     }
+    /* Eigen's GEMM (3.1, SSE2, x86-64) sums k in ascending order inside a depth block of kc = L1d / 128 terms — 2 nr RhsProgress
+     * sizeof(double) = 2 * 4 * 2 * 8 bytes of the packed right-hand panel per k, computeProductBlockingSizes — and adds the blocks'
+     * sums to the result one after the other; L1d is read from cpuid at run time.  48 KB (kc = 384: the golden files' host; the
+     * 400 amino-acid 2-mers are two blocks) unless PGM_EIGEN_L1D names another size in bytes.  Pinned by tests/golden/
+     * angle_trees.json (12 of 12 trees; 9 with one block) and a campaign of 60 random families against the reference binary. */
+    const char *l1e = getenv("PGM_EIGEN_L1D");
+    const long l1d = l1e ? atol(l1e) : 49152;
+    const uint32_t kc = (uint32_t)(l1d / 128 > 0 ? l1d / 128 : 1);
     for (uint32_t j = 0; j < nseq; ++j)
         for (uint32_t i = 0; i < nseq; ++i) {
-            double acc = 0.0;
-            for (uint32_t k = 0; k < ncols; ++k) acc += ((double)counts[(size_t)i * ncols + k] * inv[i]) * (double)counts[(size_t)j * ncols + k];
-            out[(size_t)i + (size_t)nseq * j] = acc * inv[j];
+            double res = 0.0;
+            for (uint32_t k0 = 0; k0 < ncols; k0 += kc) {
+                double part = 0.0;
+                for (uint32_t k = k0; k < ncols && k - k0 < kc; ++k) part += ((double)counts[(size_t)i * ncols + k] * inv[i]) * (double)counts[(size_t)j * ncols + k];
+                res = res + part;
+            }
+            out[(size_t)i + (size_t)nseq * j] = res * inv[j];
         }
     free(inv);
     return PGM_OK;

@@ -212,18 +212,19 @@ __global__ void __launch_bounds__(256) pgm_prealigned_kernel(PgmPaArgs A) {
 // contraction of the program.  counts: nseq x ncols int32 (row i = the k-mer counts of sequence i, ncols = DIM^K: 400 for amino
 // acids, 3721 for codons).  The reference evaluates diag(1/|c_i|) * C * C^T * diag(1/|c_j|) left to right in double:
 //     out(i, j) = (sum_k (c_ik * inv_i) * c_jk) * inv_j,     inv_i = 1 / sqrt(sum_k c_ik^2)
-// Here k runs sequentially from 0 (one fp64 multiply and one add per term, no FMA) — the summation order inside Eigen's GEMM
-// micro-kernel is not recoverable from the binary —; the norms are exact (integer sums of squares, correctly
-// rounded sqrt and reciprocal).  One thread per (i, j), 16 x 16 outputs per workgroup, the two 16-row slabs staged through LDS in
+// k ascending, one fp64 multiply and one add per term (no FMA), in depth blocks of `kc` terms whose sums are added to the result
+// one after the other: Eigen's GEMM (kc = L1d / 128 terms, 384 on the golden files' host; include/pgm_hip.h).  The norms are
+// exact (integer sums of squares, correctly rounded sqrt and reciprocal).  One thread per (i, j), 16 x 16 outputs per workgroup, the two 16-row slabs staged through LDS in
 // chunks of 64 columns (the i-slab already scaled).
 #define PGM_KC_TILE 16
 #define PGM_KC_CHUNK 64
 __global__ void __launch_bounds__(PGM_KC_TILE * PGM_KC_TILE) pgm_kmer_cosine_kernel(uint32_t nseq, uint32_t ncols, const int32_t *__restrict__ counts,
-                                                                                 const double *__restrict__ inv_norm, double *__restrict__ out) {
+                                                                                 const double *__restrict__ inv_norm, double *__restrict__ out, uint32_t kc) {
     __shared__ double sa[PGM_KC_TILE][PGM_KC_CHUNK + 1], sb[PGM_KC_TILE][PGM_KC_CHUNK + 1];
     const uint32_t tx = threadIdx.x % PGM_KC_TILE, ty = threadIdx.x / PGM_KC_TILE;
     const uint32_t i = blockIdx.y * PGM_KC_TILE + ty, j = blockIdx.x * PGM_KC_TILE + tx;
-    double acc = 0.0;
+    double acc = 0.0, res = 0.0;
+    uint32_t left = kc;   // terms left in the depth block
     for (uint32_t k0 = 0; k0 < ncols; k0 += PGM_KC_CHUNK) {
         for (uint32_t e = threadIdx.x; e < PGM_KC_TILE * PGM_KC_CHUNK; e += PGM_KC_TILE * PGM_KC_TILE) {
             const uint32_t r = e / PGM_KC_CHUNK, c = e % PGM_KC_CHUNK, k = k0 + c;
@@ -233,10 +234,14 @@ __global__ void __launch_bounds__(PGM_KC_TILE * PGM_KC_TILE) pgm_kmer_cosine_ker
         }
         __syncthreads();
         const uint32_t kn = min((uint32_t)PGM_KC_CHUNK, ncols - k0);
-        for (uint32_t c = 0; c < kn; ++c) acc = __dadd_rn(acc, __dmul_rn(sa[ty][c], sb[tx][c]));
+        for (uint32_t c = 0; c < kn; ++c) {
+            acc = __dadd_rn(acc, __dmul_rn(sa[ty][c], sb[tx][c]));
+            if (--left == 0u) { res = __dadd_rn(res, acc); acc = 0.0; left = kc; }
+        }
         __syncthreads();
     }
-    if (i < nseq && j < nseq) out[(size_t)i + (size_t)nseq * j] = __dmul_rn(acc, inv_norm[j]);
+    if (left != kc) res = __dadd_rn(res, acc);   // the last, shorter block
+    if (i < nseq && j < nseq) out[(size_t)i + (size_t)nseq * j] = __dmul_rn(res, inv_norm[j]);
 }
 __global__ void pgm_kmer_norm_kernel(uint32_t nseq, uint32_t ncols, const int32_t *__restrict__ counts, double *__restrict__ inv_norm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -3,6 +3,7 @@
 // The O(L^2) Needleman-Wunsch of every pair (alignPair) runs behind the C ABI
 // (pgm_nw_pairs_batch); ML distance estimation and neighbour joining stay on the host.
 #include "pgm_host.h"
+#include <quadmath.h>
 
 #include <algorithm>
 #include <atomic>
@@ -550,13 +551,25 @@ DistanceMatrix angleDistances(const Alphabet &a, const std::map<std::string, seq
         for (uint32_t j = i + 1; j < n; ++j) std::swap(distances.distances[(size_t)i * n + j], distances.distances[(size_t)j * n + i]);
     be.seconds_mldist += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const bool ml = cmdlineopts.mldist_flag || cmdlineopts.mldist_gap_flag;
-    for (double &d : distances.distances) {   // :101-105
-        d = -1.0 * std::log((d * d + 0.4) * (1.0 / 1.4));   // (Eigen 3.1: array / scalar multiplies by the reciprocal)
-        if (!ml) {
-            const double e = std::exp(d);
-            d = -0.5 * (5.0 * e - std::sqrt(45.0 * (e * e) - 20.0 * e)) * (1.0 / e);
+    // log and exp of the reference binary are those of the glibc it is linked with statically (2.17: IBM's correctly rounded ones);
+    // today's libm is within 0.52 ulp, which moved the exact final tie of 3 trees in 60.  Correctly rounded here: the long double
+    // function when its result is not within 2^-9 ulp of a rounding boundary, binary128 (libquadmath) otherwise.
+    auto correctly_rounded = [](long double y, __float128 (*exact)(__float128), double x) {
+        const double lo = (double)(y - fabsl(y) * 0x1p-62L), hi = (double)(y + fabsl(y) * 0x1p-62L);
+        return lo == hi ? lo : (double)exact((__float128)x);
+    };
+    auto cr_log = [&](double x) { return correctly_rounded(logl((long double)x), logq, x); };
+    auto cr_exp = [&](double x) { return correctly_rounded(expl((long double)x), expq, x); };
+    parallel_for((size_t)n, [&](size_t r) {   // :101-105, row by row on the host threads
+        for (uint32_t c = 0; c < n; ++c) {
+            double &d = distances.distances[r * n + c];
+            d = -1.0 * cr_log((d * d + 0.4) / 1.4);
+            if (!ml) {
+                const double e = cr_exp(d);
+                d = -0.5 * (5.0 * e - std::sqrt(45.0 * (e * e) - 20.0 * e)) * (1.0 / e);
+            }
         }
-    }
+    });
     for (uint32_t j = 0; j < n; ++j)   // :107-113: variances = distances / ((len_i + len_j) / 2), at least 1e-5
         for (uint32_t i = 0; i < n; ++i) {
             double v = 1.0 / ((seq_len[j] + seq_len[i]) / 2);
