@@ -283,6 +283,11 @@ int pgm_resident_reset(pgm_ctx *ctx);
  * pgm_resident_reset.  Used through pgm_site_ref and as sites1 / sites2 of pgm_merge_profiles_batch_ex. */
 int pgm_resident_onehot(pgm_ctx *ctx, uint32_t dim, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                         const double **dev);
+/* A resident matrix of another context copied into this one's resident memory (a pass sharded over several devices by subtree: the
+ * parent of two subtrees needs both children's profiles on its device; hipMemcpyPeer between devices, a device-to-device copy within
+ * one).  src must be an address pgm_merge_profiles_batch_ex / pgm_resident_onehot / pgm_resident_import returned for src_ctx and
+ * still be valid there; *dst stays valid until pgm_resident_reset(ctx). */
+int pgm_resident_import(pgm_ctx *ctx, pgm_ctx *src_ctx, const double *src, uint64_t count, const double **dst);
 float pgm_merge_last_kernel_ms(pgm_ctx *ctx);
 
 #ifdef __cplusplus

@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
 
 extern "C" {
 int pgmo_align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
@@ -27,9 +30,86 @@ namespace pgm {
 namespace {
 struct OracleBackend : Backend {
     const char *name() const override { return "oracle"; }
+    // PGM_ORACLE_RESIDENT=1: the "device-resident" profiles of the host scaffolding on this CPU backend — one arena of host memory per
+    // worker, addresses handed out like device addresses, and EVERY use checked against the arena of the worker that runs the call: the
+    // tests of the subtree-sharded pass (tests/test_cpu_host.py) fail on a profile matrix that was not copied to the worker using it.
+    struct Arena { std::vector<std::pair<std::unique_ptr<double[]>, size_t>> blocks; };
+    mutable std::mutex mu;
+    std::vector<Arena> arenas;
+    double *arena_alloc(int w, size_t count) {
+        std::lock_guard<std::mutex> g(mu);
+        if (arenas.size() <= (size_t)w) arenas.resize((size_t)w + 1);
+        arenas[(size_t)w].blocks.emplace_back(std::unique_ptr<double[]>(new double[std::max<size_t>(count, 1)]()), count);
+        return arenas[(size_t)w].blocks.back().first.get();
+    }
+    int arena_of(const double *p) const {   // worker whose arena holds p, -1: not a resident address
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t w = 0; w < arenas.size(); ++w)
+            for (const auto &b : arenas[w].blocks) if (p >= b.first.get() && p < b.first.get() + std::max<size_t>(b.second, 1)) return (int)w;
+        return -1;
+    }
+    void check_here(const double *p, int w, const char *what) const {
+        const int o = arena_of(p);
+        if (o >= 0 && o != w) error("oracle backend: %s of worker %d used on worker %d", what, o, w);
+    }
+    bool resident() const override { return getenv("PGM_ORACLE_RESIDENT") != nullptr; }
+    void resident_reset() override { std::lock_guard<std::mutex> g(mu); arenas.clear(); }
+    bool resident_onehot(uint32_t dim, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double **dev, int w) override {
+        for (uint32_t s = 0; s < nseq; ++s) {   // SequenceGraph.h:101-109: START, one column per residue (uniform without a value), END
+            const uint32_t L = offs[s + 1] - offs[s];
+            double *m = arena_alloc(w, (size_t)dim * (L + 2));
+            for (uint32_t i = 0; i < L; ++i) {
+                const int v = syms[offs[s] + i];
+                for (uint32_t k = 0; k < dim; ++k) m[(size_t)dim * (i + 1) + k] = v < 0 ? 1.0 / dim : ((int)k == v ? 1.0 : 0.0);
+            }
+            dev[s] = m;
+        }
+        return true;
+    }
+    bool merge_profiles_batch_res(uint32_t njobs, const pgm_merge_job *jobs, const double **dev, int w) override {
+        for (uint32_t i = 0; i < njobs; ++i) {
+            pgm_merge_job j = jobs[i];
+            check_here(j.sites1, w, "a child's profiles"); check_here(j.sites2, w, "a child's profiles");
+            double *m = arena_alloc(w, (size_t)j.dim * j.nnodes);
+            j.profiles = m;
+            if (pgmo_merge_profiles(&j) != PGM_OK) error("pgmo_merge_profiles failed");
+            dev[i] = m;
+        }
+        return true;
+    }
+    const double *resident_import(int dst, int src, const double *p, size_t count) override {
+        if (arena_of(p) != src) error("oracle backend: resident_import of an address that is not worker %d's", src);
+        double *m = arena_alloc(dst, count);
+        memcpy(m, p, 8 * count);
+        return m;
+    }
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
-                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int, const pgm_site_ref *, const pgm_site_ref *) override {
-        pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out);
+                            const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int w, const pgm_site_ref *res1, const pgm_site_ref *res2) override {
+        if (!res1 && !res2) { pgmo_align_graphs_batch(njobs, g1, g2, model, scores, out); return; }
+        // resident graphs: the profiles gathered through the cleaned graphs' node maps, as the device does (include/pgm_hip.h: pgm_site_ref)
+        std::vector<pgm_graph> f1(njobs), f2(njobs);
+        std::vector<const pgm_graph *> p1(njobs), p2(njobs);
+        std::vector<std::vector<double>> keep;
+        keep.reserve(2 * (size_t)njobs);
+        auto gather = [&](const pgm_graph &g, const pgm_site_ref *r) {
+            pgm_graph f = g;
+            if (r && r->dev_sites) {
+                check_here(r->dev_sites, w, "resident profiles");
+                keep.emplace_back((size_t)g.dim * g.n);
+                for (uint32_t v = 0; v < g.n; ++v) {
+                    const uint32_t c = r->node_map ? r->node_map[v] : v;
+                    if (c >= r->ncols) error("oracle backend: node map beyond the resident matrix");
+                    memcpy(&keep.back()[(size_t)g.dim * v], r->dev_sites + (size_t)g.dim * c, 8 * (size_t)g.dim);
+                }
+                f.sites = keep.back().data();
+            }
+            return f;
+        };
+        for (uint32_t i = 0; i < njobs; ++i) {
+            f1[i] = gather(*g1[i], res1 ? &res1[i] : nullptr); f2[i] = gather(*g2[i], res2 ? &res2[i] : nullptr);
+            p1[i] = &f1[i]; p2[i] = &f2[i];
+        }
+        pgmo_align_graphs_batch(njobs, p1.data(), p2.data(), model, scores, out);
     }
     // PGM_FARM_WORKERS=k: the farms of the host scaffolding (all-pairs tiles, jobs of a guide-tree level, leaves) run with k
     // host threads over this (stateless, re-entrant) CPU oracle: the 1-vs-k-workers identity tests of tests/test_cpu_host.py

@@ -65,7 +65,7 @@ EXPORTS = [
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_test_cu_shares", "pgm_align_batch_stage_times", "pgm_align_batch_job_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
     "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
-    "pgm_merge_profiles_batch", "pgm_merge_profiles_batch_ex", "pgm_resident_reset", "pgm_resident_onehot", "pgm_merge_last_kernel_ms",
+    "pgm_merge_profiles_batch", "pgm_merge_profiles_batch_ex", "pgm_resident_reset", "pgm_resident_onehot", "pgm_resident_import", "pgm_merge_last_kernel_ms",
 ]
 
 
@@ -117,6 +117,7 @@ def _load():
         "pgm_merge_profiles_batch_ex": (C.c_int, [vp, u32, C.POINTER(pgm_merge_job), u32, C.POINTER(C.POINTER(C.c_double))]),
         "pgm_resident_reset": (C.c_int, [vp]),
         "pgm_resident_onehot": (C.c_int, [vp, u32, u32, C.POINTER(C.c_int8), C.POINTER(u32), C.POINTER(C.POINTER(C.c_double))]),
+        "pgm_resident_import": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.POINTER(C.c_double))]),
         "pgm_merge_last_kernel_ms": (C.c_float, [vp]),
     }
     for name, (res, args) in sig.items():

@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 namespace pgm {
@@ -16,6 +19,10 @@ struct HipBackend : Backend {
     // pairs — to the contexts, one host thread each (farm_shards / computePwDistances).
     std::vector<pgm_ctx *> ctxs;
     std::vector<const CSProfile *> loaded;   // the profile library resident on context w
+    // Two contexts on ONE device (PGM_DEVICES=0,0: a test set-up) must not run their alignGraphs batches at the same time: every
+    // batch sizes its persistent grids for the whole device (no grid of a stage waits for a CU).  One lock per device.
+    std::map<int, std::unique_ptr<std::mutex>> device_lock;
+    std::vector<int> device_of;
     HipBackend() {
         std::vector<int> devs;
         if (const char *e = getenv("PGM_DEVICES")) {
@@ -31,6 +38,8 @@ struct HipBackend : Backend {
             if (pgm_ctx_create(d, &c) != PGM_OK || !c)
                 error("libpgm_hip: cannot create a context on device %d: %s", d, pgm_last_error());
             ctxs.push_back(c);
+            device_of.push_back(d);
+            if (!device_lock.count(d)) device_lock[d].reset(new std::mutex);
         }
         loaded.assign(ctxs.size(), nullptr);
     }
@@ -41,11 +50,19 @@ struct HipBackend : Backend {
     void align_graphs_batch(uint32_t njobs, const pgm_graph *const *g1, const pgm_graph *const *g2,
                             const pgm_model *const *model, const pgm_scores *scores, pgm_align_out *out, int worker,
                             const pgm_site_ref *res1, const pgm_site_ref *res2) override {
+        std::lock_guard<std::mutex> one_batch_per_device(*device_lock.at(device_of[(size_t)worker % ctxs.size()]));
         int rc = pgm_align_graphs_batch_res(ctx_of(worker), njobs, g1, g2, model, scores, res1, res2, out);
         if (rc != PGM_OK && rc != PGM_ERR_BACKTRACK) error("pgm_align_graphs_batch failed (%d): %s", rc, pgm_last_error());
     }
-    // resident profiles: one context only (a parent's children would otherwise live on different devices), PGM_NO_RESIDENT switches it off
-    bool resident() const override { return ctxs.size() == 1 && !getenv("PGM_NO_RESIDENT"); }
+    // resident profiles (PGM_NO_RESIDENT switches them off): with several contexts the pass is sharded by subtree and the few matrices
+    // a parent needs from another device are copied over (progressive.cpp assign_owners, resident_import)
+    bool resident() const override { return !getenv("PGM_NO_RESIDENT"); }
+    const double *resident_import(int dst, int src, const double *p, size_t count) override {
+        const double *out = nullptr;
+        int rc = pgm_resident_import(ctx_of(dst), ctx_of(src), p, (uint64_t)count, &out);
+        if (rc != PGM_OK) error("pgm_resident_import failed (%d): %s", rc, pgm_last_error());
+        return out;
+    }
     bool resident_onehot(uint32_t dim, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double **dev, int worker) override {
         int rc = pgm_resident_onehot(ctx_of(worker), dim, nseq, syms, offs, dev);
         if (rc != PGM_OK) error("pgm_resident_onehot failed (%d): %s", rc, pgm_last_error());

@@ -145,7 +145,7 @@ void farm_run(const std::vector<std::vector<uint32_t>> &shards, const std::funct
 
 std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &g1, const std::vector<const Graph *> &g2,
                                               const std::vector<const Model *> &model, const std::vector<pgm_site_ref> &res1,
-                                              const std::vector<pgm_site_ref> &res2) {
+                                              const std::vector<pgm_site_ref> &res2, const std::vector<int> *worker_of) {
     const uint32_t n = (uint32_t)g1.size();
     std::vector<pgm_graph> f1(n), f2(n);
     std::vector<pgm_model> fm(n);
@@ -181,11 +181,38 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
     // they are dealt to the workers by DP cells, longest first; every worker runs its shard as one batch on its own context.
     std::vector<uint64_t> cost(n);
     for (uint32_t i = 0; i < n; ++i) cost[i] = (uint64_t)g1[i]->size() * g2[i]->size();
-    const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
+    std::vector<std::vector<uint32_t>> shards;
+    if (worker_of && be.workers() > 1) {
+        // a pass sharded by subtree: every job runs where its children's profiles are (largest first within a worker, like farm_shards)
+        shards.assign((size_t)be.workers(), std::vector<uint32_t>());
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        for (uint32_t i : order) shards[(size_t)(*worker_of)[i] % shards.size()].push_back(i);
+    } else shards = farm_shards(cost, be.workers());
+    size_t used = 0;
+    for (const auto &sh : shards) used += !sh.empty();
     if (shards.size() <= 1) {
         be.align_graphs_batch(n, p1.data(), p2.data(), pm.data(), sc.data(), out.data(), 0, res1.empty() ? nullptr : res1.data(), res2.empty() ? nullptr : res2.data());
+    } else if (worker_of) {
+        farm_run(shards, [&](int w) {
+            const std::vector<uint32_t> &sh = shards[(size_t)w];
+            const uint32_t m = (uint32_t)sh.size();
+            std::vector<const pgm_graph *> q1(m), q2(m);
+            std::vector<const pgm_model *> qm(m);
+            std::vector<pgm_scores> qs(m);
+            std::vector<pgm_align_out> qo(m);
+            std::vector<pgm_site_ref> r1(res1.empty() ? 0 : m), r2(res2.empty() ? 0 : m);
+            for (uint32_t k = 0; k < m; ++k) {
+                q1[k] = p1[sh[k]]; q2[k] = p2[sh[k]]; qm[k] = pm[sh[k]]; qs[k] = sc[sh[k]]; qo[k] = out[sh[k]];
+                if (!res1.empty()) r1[k] = res1[sh[k]];
+                if (!res2.empty()) r2[k] = res2[sh[k]];
+            }
+            be.align_graphs_batch(m, q1.data(), q2.data(), qm.data(), qs.data(), qo.data(), w, r1.empty() ? nullptr : r1.data(), r2.empty() ? nullptr : r2.data());
+            for (uint32_t k = 0; k < m; ++k) out[sh[k]] = qo[k];
+        });
     } else {
-        if (!res1.empty() || !res2.empty()) error("alignGraphsBatch: profiles resident on one device cannot be dealt to several");
+        if (!res1.empty() || !res2.empty()) error("alignGraphsBatch: resident profiles need the jobs' workers (worker_of)");
         farm_run(shards, [&](int w) {
             const std::vector<uint32_t> &sh = shards[(size_t)w];
             const uint32_t m = (uint32_t)sh.size();
@@ -198,7 +225,7 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
             for (uint32_t k = 0; k < m; ++k) out[sh[k]] = qo[k];
         });
     }
-    be.farm_level_workers = std::max(be.farm_level_workers, (int)shards.size());
+    be.farm_level_workers = std::max(be.farm_level_workers, (int)std::max<size_t>(used, 1));
     be.seconds_align += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t i = 0; i < n; ++i) {
         if (out[i].status != PGM_OK) error("backtracking failed");  // GraphAlign.h:410

@@ -146,9 +146,9 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         Backend &be = default_backend();
         fprintf(stderr,
                 "{\"backend\": \"%s\", \"init_s\": %.6f, \"tree_s\": %.6f, \"progressive_s\": %.6f, \"align_cells\": %llu, \"align_s\": %.6f, "
-                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"merge_profiles_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d, \"farm_level_workers\": %d, \"farm_leaf_workers\": %d}\n",
+                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"merge_profiles_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d, \"farm_level_workers\": %d, \"farm_leaf_workers\": %d, \"resident\": %s, \"resident_imports\": %d}\n",
                 be.name(), t_init, t_tree, t_prog, (unsigned long long)be.cells_aligned, be.seconds_align,
-                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.seconds_merge_profiles, be.farm_workers, be.farm_tiles, be.farm_level_workers, be.farm_leaf_workers);
+                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.seconds_merge_profiles, be.farm_workers, be.farm_tiles, be.farm_level_workers, be.farm_leaf_workers, be.resident_pass ? "true" : "false", be.resident_imports);
     }
     return 0;
 }

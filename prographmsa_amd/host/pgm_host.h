@@ -248,6 +248,9 @@ struct Backend {
     virtual bool resident_onehot(uint32_t, uint32_t, const int8_t *, const uint32_t *, const double **, int = 0) { return false; }   // leaf graphs built on the device
     virtual void resident_reset() {}   // start of a progressive pass: the previous pass's device-resident profiles are dead
     virtual bool merge_profiles_batch_res(uint32_t, const pgm_merge_job *, const double **, int = 0) { return false; }
+    // a resident matrix of worker `src` copied to worker `dst` (a pass sharded by subtree: the parent of two subtrees needs both children's
+    // profiles where it runs); the address on `dst`, valid like every resident address until resident_reset
+    virtual const double *resident_import(int /*dst*/, int /*src*/, const double *, size_t /*count*/) { return nullptr; }
     // One tile of alignPair jobs in two halves (include/pgm_hip.h: pgm_nw_pairs_submit / pgm_nw_pairs_wait): a worker keeps two
     // tiles in flight.  flags & PGM_NW_REDUCED: counts = (ident, total) per pair.  Result buffers come from host_alloc.
     virtual int nw_pairs_submit(uint32_t dim, const int32_t *score, int32_t go, int32_t ge, uint32_t nseq,
@@ -272,6 +275,7 @@ struct Backend {
                                         const uint64_t *out_offs, int worker = 0) = 0;
     int farm_workers = 0, farm_tiles = 0;   // what the last all-pairs farm used (logs / --stats)
     int farm_level_workers = 0, farm_leaf_workers = 0;   // most workers a guide-tree level's jobs / the leaves' profiles were dealt to
+    bool resident_pass = false; int resident_imports = 0;   // the last progressive pass kept its profiles on the devices; matrices copied between them
     uint64_t cells_aligned = 0;   // Σ (n1-2)(n2-2)
     uint64_t cells_nw = 0;        // Σ L1*L2
     double seconds_align = 0, seconds_nw = 0, seconds_mldist = 0;
@@ -293,7 +297,8 @@ std::vector<AlignmentResult> alignGraphsBatch(const std::vector<const Graph *> &
                                               const std::vector<const Graph *> &g2,
                                               const std::vector<const Model *> &model,
                                               const std::vector<pgm_site_ref> &res1 = std::vector<pgm_site_ref>(),
-                                              const std::vector<pgm_site_ref> &res2 = std::vector<pgm_site_ref>());
+                                              const std::vector<pgm_site_ref> &res2 = std::vector<pgm_site_ref>(),
+                                              const std::vector<int> *worker_of = nullptr);   // (given: job k runs on worker (*worker_of)[k] — where its profiles are)
 // mergeGraphs (GraphAlign.h:550-727)
 // mergeGraphs in three parts, so that the profiles of all merges of a guide-tree level can be computed in one device batch:
 //   planMerge     the "unify" walk over the two mappings (GraphAlign.h:569-620 without the arithmetic): per node of the

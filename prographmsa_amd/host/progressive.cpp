@@ -197,6 +197,52 @@ std::map<std::string, std::vector<repeat_t>> read_repeats(const Alphabet &a, con
     return map;
 }
 
+// A resident pass on several device contexts: the guide tree is cut into subtrees — the most expensive subtree of the cut is replaced
+// by its two children until there are three per worker (or only leaves are left) —, the subtrees are dealt to the workers by cost
+// (longest first to the least loaded: farm_shards), and every node of a subtree belongs to its worker: leaves are built there, jobs
+// run there, merged profiles stay there.  A node above the cut belongs to the worker of its more expensive child; the other child's
+// profiles are copied over once (Backend::resident_import).  cost(node) = sum over the internal nodes below of the product of the
+// children's mean leaf lengths: the DP cells, near enough.  `nodes` is in post-order (children before parents).
+static std::vector<int> assign_owners(const std::vector<Node> &nodes, int root, int nworkers, const std::vector<double> &leaf_len) {
+    const size_t n = nodes.size();
+    std::vector<double> cost(n, 0.0), len_sum(n, 0.0), nleaf(n, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        if (nodes[i].child[0] < 0) { len_sum[i] = leaf_len[i]; nleaf[i] = 1.0; continue; }
+        const int c0 = nodes[i].child[0], c1 = nodes[i].child[1];
+        len_sum[i] = len_sum[c0] + len_sum[c1]; nleaf[i] = nleaf[c0] + nleaf[c1];
+        cost[i] = cost[c0] + cost[c1] + (len_sum[c0] / nleaf[c0]) * (len_sum[c1] / nleaf[c1]);
+    }
+    std::vector<int> owner(n, 0);
+    if (nworkers <= 1) return owner;
+    std::vector<int> cut{root};
+    std::vector<char> above(n, 0);
+    while (cut.size() < 3 * (size_t)nworkers) {
+        int pick = -1;
+        for (size_t k = 0; k < cut.size(); ++k)
+            if (nodes[cut[k]].child[0] >= 0 && (pick < 0 || cost[cut[k]] > cost[cut[(size_t)pick]])) pick = (int)k;
+        if (pick < 0) break;
+        const int v = cut[(size_t)pick];
+        above[v] = 1;
+        cut[(size_t)pick] = nodes[v].child[0];
+        cut.push_back(nodes[v].child[1]);
+    }
+    std::vector<uint64_t> c64(cut.size());
+    for (size_t k = 0; k < cut.size(); ++k) c64[k] = (uint64_t)cost[cut[k]] + 1u;
+    const std::vector<std::vector<uint32_t>> shards = farm_shards(c64, nworkers);
+    for (size_t w = 0; w < shards.size(); ++w)
+        for (uint32_t k : shards[w]) {
+            std::vector<int> stack{cut[k]};
+            while (!stack.empty()) {
+                const int v = stack.back(); stack.pop_back();
+                owner[v] = (int)w;
+                if (nodes[v].child[0] >= 0) { stack.push_back(nodes[v].child[0]); stack.push_back(nodes[v].child[1]); }
+            }
+        }
+    for (size_t i = 0; i < n; ++i)   // post-order: the children of a node above the cut have their owners
+        if (above[i]) owner[i] = cost[nodes[i].child[0]] + nleaf[nodes[i].child[0]] >= cost[nodes[i].child[1]] + nleaf[nodes[i].child[1]] ? owner[nodes[i].child[0]] : owner[nodes[i].child[1]];
+    return owner;
+}
+
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
                                                  const PhyTree &tree, const CSProfile *csprofile,
                                                  const ModelFactory &model_factory,
@@ -218,6 +264,15 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
     // copied into the staging block and uploaded for the alignments, and once more for the merges)
     const bool resident_pass = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active();
     const bool resident_leaves = resident_pass && !csprofile;
+    // where the profiles of every node live (worker = device context): all 0 with one context
+    std::vector<int> owner(nodes.size(), 0);
+    if (resident_pass && default_backend().workers() > 1) {
+        std::vector<double> leaf_len(nodes.size(), 0.0);
+        for (int li : leaves) leaf_len[(size_t)li] = (double)sequences.at(nodes[li].tree->getName()).size();
+        owner = assign_owners(nodes, root, default_backend().workers(), leaf_len);
+    }
+    default_backend().resident_pass = resident_pass;
+    default_backend().resident_imports = 0;
     parallel_for(leaves.size(), [&](size_t k) {   // (independent leaves: a thousand SequenceGraphs are 50 ms on one thread)
         Node &nd = nodes[leaves[k]];
         auto it = sequences.find(nd.tree->getName());
@@ -237,16 +292,22 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         }
     });
     if (resident_leaves && !leaves.empty()) {
-        std::vector<int8_t> syms;
-        std::vector<uint32_t> offs(leaves.size() + 1, 0);
-        for (size_t s = 0; s < leaves.size(); ++s) {
-            const sequence_t &seq = sequences.at(nodes[leaves[s]].tree->getName());
-            for (int8_t c : seq) syms.push_back(a.isValid(c) ? (int8_t)a.value(c) : (int8_t)-1);
-            offs[s + 1] = (uint32_t)syms.size();
+        const int nw = default_backend().workers();
+        for (int w = 0; w < nw; ++w) {   // every worker builds the leaves of its subtrees
+            std::vector<int> mine;
+            for (int li : leaves) if (owner[(size_t)li] == w) mine.push_back(li);
+            if (mine.empty()) continue;
+            std::vector<int8_t> syms;
+            std::vector<uint32_t> offs(mine.size() + 1, 0);
+            for (size_t s = 0; s < mine.size(); ++s) {
+                const sequence_t &seq = sequences.at(nodes[mine[s]].tree->getName());
+                for (int8_t c : seq) syms.push_back(a.isValid(c) ? (int8_t)a.value(c) : (int8_t)-1);
+                offs[s + 1] = (uint32_t)syms.size();
+            }
+            std::vector<const double *> dev(mine.size(), nullptr);
+            if (!default_backend().resident_onehot((uint32_t)a.DIM, (uint32_t)mine.size(), syms.data(), offs.data(), dev.data(), w)) error("the backend could not build the leaf graphs on the device");
+            for (size_t s = 0; s < mine.size(); ++s) nodes[mine[s]].res.graph.setDevSites(dev[s]);
         }
-        std::vector<const double *> dev(leaves.size(), nullptr);
-        if (!default_backend().resident_onehot((uint32_t)a.DIM, (uint32_t)leaves.size(), syms.data(), offs.data(), dev.data(), 0)) error("the backend could not build the leaf graphs on the device");
-        for (size_t s = 0; s < leaves.size(); ++s) nodes[leaves[s]].res.graph.setDevSites(dev[s]);
     }
     if (csprofile) {
         // SequenceGraph(seq, csprofile, model_factory.getModel(branch_length)) for every leaf in one
@@ -338,6 +399,20 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         const size_t L = level.size();
         std::vector<Pending> pend(L);
         const auto tp0 = std::chrono::steady_clock::now();
+        if (resident_pass)   // children of a node above the cut of the subtrees: the profiles of the one on another worker are copied over
+            for (size_t k = 0; k < L; ++k) {
+                const Node &nd = nodes[level[k]];
+                for (int c = 0; c < 2; ++c) {
+                    const int ch = nd.child[c];
+                    Graph &g = nodes[ch].res.graph;
+                    if (owner[(size_t)ch] == owner[(size_t)level[k]] || !g.devSites()) continue;
+                    const double *there = default_backend().resident_import(owner[(size_t)level[k]], owner[(size_t)ch], g.devSites(), (size_t)a.DIM * g.size());
+                    if (!there) error("the backend could not copy resident profiles between its workers");
+                    g.setDevSites(there);
+                    owner[(size_t)ch] = owner[(size_t)level[k]];
+                    ++default_backend().resident_imports;
+                }
+            }
         parallel_for(L, [&](size_t k) {
             Node &nd = nodes[level[k]];
             const ProgressiveAlignmentResult &r1 = nodes[nd.child[0]].res, &r2 = nodes[nd.child[1]].res;
@@ -369,7 +444,9 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 }
             }
         }
-        std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm, rs1, rs2);
+        std::vector<int> worker_of(L, 0);
+        for (size_t k = 0; k < L; ++k) worker_of[k] = owner[(size_t)level[k]];
+        std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm, rs1, rs2, resident_pass && default_backend().workers() > 1 ? &worker_of : nullptr);
         const auto tp2 = std::chrono::steady_clock::now();
         // mergeGraphs of the whole level: plans on host threads, the node profiles (P g products, L2 normalisation: the
         // arithmetic of the merge) in ONE device batch, then edges / Graph / extend_alignment on host threads again
@@ -408,7 +485,22 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 std::vector<uint64_t> cost(L);
                 for (size_t k = 0; k < L; ++k) cost[k] = mj[k].nnodes;
                 const std::vector<std::vector<uint32_t>> shards = farm_shards(cost, be.workers());
-                if (resident) {
+                if (resident && be.workers() > 1) {   // every merge where its children are: one batch per worker, concurrently
+                    std::vector<std::vector<uint32_t>> mine((size_t)be.workers());
+                    for (size_t k = 0; k < L; ++k) mine[(size_t)worker_of[k]].push_back((uint32_t)k);
+                    std::vector<char> ok(mine.size(), 1);
+                    farm_run(mine, [&](int w) {
+                        const std::vector<uint32_t> &sh = mine[(size_t)w];
+                        std::vector<pgm_merge_job> q(sh.size());
+                        std::vector<const double *> dv(sh.size(), nullptr);
+                        for (size_t k = 0; k < sh.size(); ++k) q[k] = mj[sh[k]];
+                        ok[(size_t)w] = be.merge_profiles_batch_res((uint32_t)q.size(), q.data(), dv.data(), w) ? 1 : 0;
+                        for (size_t k = 0; k < sh.size(); ++k) dev_profiles[sh[k]] = dv[k];
+                    });
+                    on_device = true;
+                    for (char c : ok) on_device = on_device && c;
+                    if (!on_device) error("the backend could not keep the merged profiles on the device");
+                } else if (resident) {
                     on_device = be.merge_profiles_batch_res((uint32_t)L, mj.data(), dev_profiles.data(), 0);
                     if (!on_device) error("the backend could not keep the merged profiles on the device");
                 } else if (shards.size() <= 1) {

@@ -160,6 +160,32 @@ def test_level_and_leaf_farm_one_vs_k_workers(oracle_build, case, flags, gold):
         assert outs[1] == open(os.path.join(GOLD, gold)).read()
 
 
+@pytest.mark.parametrize("case,flags,gold", [("c2.fa", ["--fasta", "-t", os.path.join(GOLD, "c2.tree")], "c2.out.fa"),
+                                             ("c1.fa", ["--fasta", "-t", os.path.join(GOLD, "c1.tree"), "--cs_profile", os.path.join(GOLD, "K50.lib")], "c1.cs.out.fa"),
+                                             ("c1.fa", ["--fasta", "-a"], "c1.a_iter.out.fa"),
+                                             ("cd1.fa", ["--codon", "--fasta", "-t", os.path.join(GOLD, "cd1.tree")], "cd1.out.fa")])
+def test_resident_pass_sharded_by_subtree(oracle_build, case, flags, gold):
+    """A pass whose profiles never leave the devices, on several of them (host/progressive.cpp assign_owners): the guide tree is cut into
+    three subtrees per worker, every node of a subtree lives on its worker (leaves built there, jobs and merges run there), a node above
+    the cut on the worker of its larger child, and the other child's matrix is copied over once (Backend::resident_import).  The oracle
+    backend plays the devices with one arena of host memory per worker and refuses a matrix used on a worker that does not hold it.
+    1, 2, 3 and 5 workers: identical FASTA, the reference's; resident, with copies only where the tree is cut."""
+    exe = os.path.join(oracle_build, "pgmsa_oracle")
+    for workers in (1, 2, 3, 5):
+        env = dict(os.environ, PGM_FARM_WORKERS=str(workers), PGM_ORACLE_RESIDENT="1")
+        r = subprocess.run([exe] + flags + ["--stats", os.path.join(GOLD, case)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith('{"backend"')][-1])
+        assert st["resident"] is True
+        nseq = open(os.path.join(GOLD, case)).read().count(">")
+        if workers == 1:
+            assert st["resident_imports"] == 0
+        else:
+            assert 0 < st["resident_imports"] <= min(3 * workers, nseq) - 1   # at most one copy per node above the cut
+            assert st["farm_level_workers"] == min(workers, nseq // 2)
+        assert r.stdout == open(os.path.join(GOLD, gold)).read(), workers
+
+
 def test_farm_shards_cover_every_unit_once():
     """farm_shards is exercised through the driver above; its contract (every unit in exactly one shard, longest first, least
     loaded worker) is restated here on the Python twin that bench.py uses for the process-per-GPU launch."""
