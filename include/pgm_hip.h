@@ -101,7 +101,9 @@ int pgm_align_graphs_batch(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
  *   run     : launch the prep, emission and fill(+traceback) kernels on the context's stream (asynchronous)
  *   fetch   : wait for the stream, then copy score / mappings from the batch's pinned result block (written by the kernel
  *             itself while it runs) into caller memory
- * bench.py times `run` with the inputs already resident. */
+ * bench.py times `run` with the inputs already resident.
+ * A stage sizes its persistent grids for the WHOLE device: between `run` and the end of `fetch` no other batch may run on that
+ * device (pgm_align_graphs_batch serialises the contexts of one device itself; callers of the staged form do it themselves). */
 int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                            const pgm_graph *const *g2, const pgm_model *const *model,
                            const pgm_scores *scores, pgm_align_batch **out);

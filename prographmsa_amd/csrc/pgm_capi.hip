@@ -1570,8 +1570,15 @@ int pgm_align_graphs_batch_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     int rc = pgm_align_batch_create_res(ctx, njobs, g1, g2, model, scores, 0u, res1, res2, &b);
     if (rc != PGM_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = pgm_align_batch_run(ctx, b);
-    if (rc == PGM_OK) rc = pgm_align_batch_fetch(ctx, b, out);
+    {
+        // One stage of persistent grids per DEVICE at a time: every batch sizes its grids for the whole device (no grid of a stage waits
+        // for a CU, see pgm_tb_kernel's header), so two contexts on one device take turns here.  (Callers of the create / run / fetch
+        // interface with several contexts on a device have to do the same.)
+        static std::mutex device_turn[64];
+        std::lock_guard<std::mutex> turn(device_turn[(unsigned)ctx->device % 64u]);
+        rc = pgm_align_batch_run(ctx, b);
+        if (rc == PGM_OK) rc = pgm_align_batch_fetch(ctx, b, out);
+    }
     const auto t2 = std::chrono::steady_clock::now();
     pgm_align_batch_destroy(ctx, b);
     if (prof)
