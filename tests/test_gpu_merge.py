@@ -204,3 +204,48 @@ def test_resident_onehot_leaves_against_the_oracle(ctx):
         got = cj.results()[0]
         assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
         assert np.array_equal(got["map1"], ref["map1"]) and np.array_equal(got["map2"], ref["map2"])
+
+
+def test_resident_import_between_contexts(ctx):
+    """pgm_resident_import: a resident matrix of one context copied into another's resident memory (the pass sharded by subtree,
+    host/progressive.cpp) — two contexts on this one device: the copy gives the same alignment as the original, an address that is
+    not a resident one of the source context is refused, and the source stays valid."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    import oracle_lib
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    other = pg.Context(0)
+    D = 20
+    rng = np.random.default_rng(77)
+    lens = [90, 110]
+    syms = [rng.integers(0, D, L).astype(np.int8) for L in lens]
+    flat = np.concatenate(syms).astype(np.int8)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    dev = (C.POINTER(C.c_double) * 2)()
+    pg.check(pg.lib.pgm_resident_reset(ctx.handle)); pg.check(pg.lib.pgm_resident_reset(other.handle))
+    pg.check(pg.lib.pgm_resident_onehot(ctx.handle, D, 2, P(flat, C.c_int8), P(offs, C.c_uint32), dev))
+    there = (C.POINTER(C.c_double) * 2)()
+    for k in range(2):
+        got = C.POINTER(C.c_double)()
+        pg.check(pg.lib.pgm_resident_import(other.handle, ctx.handle, dev[k], D * (lens[k] + 2), C.byref(got)))
+        there[k] = got
+    bogus = C.POINTER(C.c_double)()
+    host = np.zeros(64)
+    assert pg.lib.pgm_resident_import(other.handle, ctx.handle, P(host, C.c_double), 64, C.byref(bogus)) == pg.PGM_ERR_INVALID
+    def columns(s):
+        m = np.zeros((len(s) + 2, D))
+        for i, v in enumerate(s): m[i + 1, v] = 1.0
+        return m
+    job = J.random_job(4343, lens[0] + 2, lens[1] + 2, dim=D, skip_frac=0.0, drop_chain_frac=0.0)
+    job.g1.sites = columns(syms[0]).reshape(-1); job.g2.sites = columns(syms[1]).reshape(-1)
+    ref = oracle_lib.align_graphs(job)
+    for handle, where in ((other.handle, there), (ctx.handle, dev)):
+        cj = J.CJobs([job])
+        r1 = (pg.pgm_site_ref * 1)(); r2 = (pg.pgm_site_ref * 1)()
+        r1[0].dev_sites, r1[0].node_map, r1[0].ncols = where[0], None, lens[0] + 2
+        r2[0].dev_sites, r2[0].node_map, r2[0].ncols = where[1], None, lens[1] + 2
+        pg.check(pg.lib.pgm_align_graphs_batch_res(handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out))
+        got = cj.results()[0]
+        assert np.float32(got["score"]).view(np.uint32) == np.float32(ref["score"]).view(np.uint32)
+        assert np.array_equal(got["map1"], ref["map1"]) and np.array_equal(got["map2"], ref["map2"])
+    other.close()
