@@ -66,6 +66,17 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
     const uint32_t n = first ? J.n1 : J.n2;
     const uint32_t v0 = blockIdx.z * NODES;
     if (v0 >= n) return;   // no nodes for this slice
+    if (J.tabhdr && J.tabhdr[0] == 0) {
+        // two sequence graphs (PgmJob::cls1): the scores come from a table built from ONE node per class, the walk reads decision bits
+        // and the END node's edge record — nothing of the other nodes is needed.  This slice only works if it holds one of those nodes.
+        const uint32_t nc = J.dim + 2u;
+        bool any = n - 1u >= v0 && n - 1u < v0 + (uint32_t)NODES;   // (pgm_traceback_chain: tb1[n1 - 1], tb2[n2 - 1])
+        for (uint32_t c = 0; c < nc; ++c) {
+            const uint32_t r = (uint32_t)J.tabhdr[1u + (first ? 0u : nc) + c];
+            any = any || (r != 0u && r - 1u >= v0 && r - 1u < v0 + (uint32_t)NODES);
+        }
+        if (!any) return;
+    }
     const uint32_t D = J.dim, DP = J.dp, ST = D + 1;
     float *Mf = prep_lds;
     float *pif = prep_lds + D * D;
@@ -147,6 +158,41 @@ __global__ void __launch_bounds__(NODES) pgm_prep_kernel(const PgmJob *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Classes of the nodes of the lean jobs' graphs (PgmJob::cls1 / cls2 / tabhdr), once per batch (the inputs of a batch do not change
+// between its launches): grid = (njobs, 2, slices), one thread per node.  The class is decided on the float value of the column, as
+// pgm_prep_kernel casts it.
+#define PGM_TAB_HDR 128   /* ints per job: [0] some node without a class, [1 ..] a node + 1 per class of graph 1, then of graph 2 */
+__global__ void __launch_bounds__(256) pgm_classify_kernel(const PgmJob *__restrict__ jobs) {
+    const PgmJob &J = jobs[blockIdx.x];
+    if (!J.tabhdr) return;
+    const bool first = blockIdx.y == 0;
+    const uint32_t n = first ? J.n1 : J.n2, D = J.dim;
+    const double *sites = first ? J.sites1 : J.sites2;
+    const uint32_t *smap = first ? J.smap1 : J.smap2;
+    uint8_t *cls = (uint8_t *)(first ? J.cls1 : J.cls2);
+    const float uni = (float)(1.0 / (double)D);
+    for (uint32_t v = blockIdx.z * blockDim.x + threadIdx.x; v < n; v += gridDim.z * blockDim.x) {
+        const double *col = sites + (size_t)D * (smap ? smap[v] : v);
+        uint32_t nz = 0, sym = 0;
+        bool same = true;
+        float vs = 0.f;
+        const float g0 = (float)col[0];
+        for (uint32_t k = 0; k < D; ++k) {
+            const float g = (float)col[k];
+            if (g != 0.0f) { ++nz; sym = k; vs = g; }
+            same = same && g == g0;
+        }
+        uint32_t c = 255u;
+        if (nz == 0u) c = D + 1u;
+        else if (nz == 1u && vs == 1.0f) c = sym;
+        else if (same && g0 == uni) c = D;
+        cls[v] = (uint8_t)c;
+        if (c == 255u) atomicOr(J.tabhdr, 1);
+        else atomicCAS(J.tabhdr + 1 + (first ? 0u : D + 2u) + c, 0, (int)v + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cell addressing (see PgmJob): cell = float4 {M, X, W, Y}
 // (jobs of the fill kernel: one row per lane; the lean kernel keeps no cells unless asked to and never reads them back)
 __device__ __forceinline__ size_t pgm_cell_index(const PgmJob &J, uint32_t y, uint32_t x) {
@@ -193,6 +239,7 @@ __global__ void __launch_bounds__(4 * PGM_ROWS) pgm_emission_skew_kernel(const P
     // owns row 64 R b + R l + r, at step t column t - l as ever); scores land at [(b nblk + tb) R + r][lane][8]
     const uint32_t rsh = J.rshift, nvb = J.nb << rsh;
     if (tb0 >= J.nblk || 4u * RB * blockIdx.y >= nvb) return;
+    if (J.tabhdr && pgm_gld(J.tabhdr) == 0) return;   // two sequence graphs: pgm_lean_kernel looks the scores up (PgmJob::cls1)
     auto row_of = [&](uint32_t v, uint32_t lane_) { return ((((v >> rsh) << 6) + lane_) << rsh) | (v & ((1u << rsh) - 1u)); };
     auto sblock_of = [&](uint32_t v, uint32_t tb_) { return ((((size_t)(v >> rsh) * J.nblk + tb_) << rsh) | (v & ((1u << rsh) - 1u))); };
     const uint32_t t0 = tb0 * PGM_BLOCK;
@@ -1910,7 +1957,10 @@ __device__ __forceinline__ void pgm_sweep_band(const PgmJob &J, const uint32_t b
 // 32-bit word per lane, row and block of eight steps (step i of the block in bits 31-4i .. 28-4i),
 // codes[((b nblk + t / 8) R + r) 64 + lane].
 #define PGM_LEAN_RING 512   // columns per ring (4 KB per wavefront)
-template <int R, bool KEEP>
+// TAB: the scores are looked up in the job's class table (LDS, behind the rings: PGM_LEAN_TAB_OFF) instead of read from S — the
+// class of the column travels down the lanes with the column's chain cost.
+#define PGM_LEAN_TAB_OFF (8 * PGM_LEAN_RING * 8)
+template <int R, bool KEEP, bool TAB = false>
 __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave, const int lane, uint8_t *pool, int *lsync_generic,
                                                 int *abort_flag, bool &aborted, const uint32_t spin_limit) {
     constexpr int BL = PGM_BLOCK, RING = PGM_LEAN_RING;
@@ -1926,15 +1976,18 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
     const float4 *ni2q = (const float4 *)J.ni2;
     // the END node's predecessor cell (n1-2, n2-2): band, lane, row of the lane, step (all wave-uniform)
     const uint32_t ye = n1 - 2u, be = ye / (64u * R), le = (ye % (64u * R)) / R, re = ye % R, te = (ncol - 1u) + le;
+    const __attribute__((address_space(3))) float *tab = (const __attribute__((address_space(3))) float *)(pool + PGM_LEAN_TAB_OFF);
+    const uint32_t NC = J.dim + 2u;
     uint32_t q = 0;
     for (uint32_t b = (uint32_t)wave; b < nb && !aborted; b += PGM_WAVES, ++q) {
         const uint32_t y0 = (64u * b + (uint32_t)lane) * (uint32_t)R;
         float ccy[R], gox[R];
-        uint32_t soff[R];
+        uint32_t soff[R], trow[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t y = y0 + (uint32_t)r;
             const bool valid = y + 1 < n1;
+            trow[r] = TAB ? (uint32_t)pgm_gld(J.cls1 + (valid ? y : 0u)) * NC : 0u;   // (rows beyond the graph: the START row's scores, as the emission kernel)
             ccy[r] = pgm_gload4((const float4 *)(J.ni1 + (valid ? y : 0u))).x;   // (+inf for START and for the rows below the matrix)
             gox[r] = (valid && y == 0) ? sg : gi;
             // (a row below the matrix: 0x40000000, a step outside the columns: 0x80000000 — any sum of the two lies beyond the
@@ -1951,8 +2004,9 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
         // short): emission scores (R x 16 per lane) and, in every lane l, the chain cost of column T0 + (l & 15) (column 0 has
         // no predecessor; its cost is never looked at with a finite left operand: 0 stands in)
         float4 pfs[R][2 * BL / 4];
-        float pfc = 0.f;
+        float pfc = 0.f, pfk = 0.f;   // (pfk: the class of the column, an integer in a float register like the cost it travels with)
         auto load_s_super = [&](uint32_t tb) {   // blocks tb, tb + 1
+            if (TAB) return;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t tbh = min(tb + (uint32_t)h, nblk - 1u);
@@ -1967,9 +2021,11 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
             float v = 0.f;
             if (col != 0 && col < ncol) v = pgm_gload4(ni2q + 5u * col).x;
             pfc = v;
+            if (TAB) pfk = __uint_as_float(col <= ncol ? (uint32_t)pgm_gld(J.cls2 + col) : NC - 1u);   // (columns beyond the graph: empty)
         };
         float Sc[R][2 * BL];
         auto take_super = [&]() {
+            if (TAB) return;
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -1978,14 +2034,14 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
         load_s_super(0);
         load_c_super(0);
         take_super();
-        float cblk = pfc;
+        float cblk = pfc, kblk = pfk;
         load_s_super(2);
         load_c_super(2 * BL);
         float W_left[R], X_left[R];
         uint32_t cw[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { W_left[r] = PGM_NEG_INF; X_left[r] = PGM_NEG_INF; cw[r] = 0u; }
-        float W_diag0 = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF, ccx_o = 0.f;
+        float W_diag0 = PGM_NEG_INF, W_o = PGM_NEG_INF, Y_o = PGM_NEG_INF, ccx_o = 0.f, kc_o = __uint_as_float(NC - 1u);
         int p_seen = has_prev ? 0 : 0x7fffffff, c_seen = has_next ? 0 : 0x7fffffff;
         // one block of eight steps (hc: first / second half of the super-block)
         auto block = [&](const uint32_t t0, auto hc) {
@@ -2042,6 +2098,13 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
                 const float ccx = pgm_dpp_wave_shr1(ccx_o, cblk);
                 const float W_up0 = pgm_dpp_wave_shr1(W_o, inW);
                 const float Y_up0 = pgm_dpp_wave_shr1(Y_o, inY);
+                float kc = 0.f, Sv[R];
+                if (TAB) {
+                    kc = pgm_dpp_wave_shr1(kc_o, kblk);
+                    if (H == 0 || i + 1 < BL) kblk = rot(kblk);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) Sv[r] = tab[trow[r] + __float_as_uint(kc)];
+                }
                 if (H == 0 || i + 1 < BL) cblk = rot(cblk);
                 if (i + 1 < BL) { inW = rot(inW); inY = rot(inY); }
                 const float gopen_y = (xs == 0) ? sg : gi;
@@ -2050,7 +2113,7 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
                 float W_up = W_up0, Y_up = Y_up0, W_dg = W_diag0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_dg, Sc[r][H * BL + i]), ccy[r]), ccx);
+                    const float Mv = __fsub_rn(__fsub_rn(__fadd_rn(W_dg, TAB ? Sv[r] : Sc[r][H * BL + i]), ccy[r]), ccx);
                     const float ax = __fadd_rn(X_left[r], ge), ay = __fadd_rn(Y_up, ge);
                     const float Xv = __fsub_rn(fmaxf(ax, __fadd_rn(W_left[r], gox[r])), ccx);
                     const float Yv = __fsub_rn(fmaxf(ay, __fadd_rn(W_up, gopen_y)), ccy[r]);
@@ -2077,7 +2140,7 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
                     if (i == BL - 1) codes_band[(size_t)((t0 / BL) * R + r) * 64u] = w;
                 }
                 W_diag0 = W_up0;
-                W_o = W_up; Y_o = Y_up; ccx_o = ccx;
+                W_o = W_up; Y_o = Y_up; ccx_o = ccx; kc_o = kc;
                 if (has_next) {   // lane 63 completes column t - 63 of the band's last row: slot and validity are wave-uniform
                     const uint32_t xc = t - 63u;
                     if (xc < ncol) {
@@ -2109,7 +2172,7 @@ __device__ __forceinline__ void pgm_sweep_chain(const PgmJob &J, const int wave,
             const uint32_t T1 = T0 + 2 * BL;
             if (T1 >= tsteps) break;
             take_super();
-            cblk = pfc;
+            cblk = pfc; kblk = pfk;
             load_s_super(T1 / BL + 2u);
             load_c_super(T1 + 2 * BL);
         }
@@ -2991,7 +3054,28 @@ __global__ void __launch_bounds__(64 * PGM_WAVES, 2) pgm_lean_kernel(const PgmJo
         if (it < 0) break;
         const PgmJob &J = jobs[list[it]];
         if (trace && threadIdx.x == 0) { trace[6 * it] = blockIdx.x; trace[6 * it + 1] = __builtin_amdgcn_s_memrealtime(); trace[6 * it + 2] = 0; trace[6 * it + 3] = 0; trace[6 * it + 4] = 0; trace[6 * it + 5] = 0; }
-        if (J.keep_cells) pgm_sweep_chain<R, true>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
+        const bool tabmode = J.tabhdr != nullptr && pgm_gld(J.tabhdr) == 0;   // (wave-uniform: every node of both graphs has a class)
+        if (tabmode) {
+            // the job's score table: entry (class of the row, class of the column) from one node of either class, with the operations of
+            // pgm_emission_skew_kernel (terms in ascending order, one multiply and one add each, then pgm_emission_finish)
+            float *tabw = (float *)(pool + PGM_LEAN_TAB_OFF);
+            const uint32_t NC = J.dim + 2u, DP = J.dp;
+            const float mi = J.sc.match_init;
+            for (uint32_t e = threadIdx.x; e < NC * NC; e += 64u * PGM_WAVES) {
+                const int r1 = pgm_gld(J.tabhdr + 1 + e / NC), r2 = pgm_gld(J.tabhdr + 1 + NC + e % NC);
+                float v = 0.f;
+                if (r1 != 0 && r2 != 0) {
+                    const float *g = J.g1f + (size_t)DP * (uint32_t)(r1 - 1), *tc = J.t2 + (size_t)DP * (uint32_t)(r2 - 1);
+                    float acc = 0.0f;
+                    for (uint32_t k = 0; k < DP; ++k) acc = __fadd_rn(acc, __fmul_rn(pgm_gld(g + k), pgm_gld(tc + k)));
+                    v = pgm_emission_finish(acc, pgm_gld(J.a1 + (r1 - 1)), pgm_gld(J.b2 + (r2 - 1)), mi);
+                }
+                tabw[e] = v;
+            }
+            __syncthreads();
+            pgm_sweep_chain<R, false, true>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
+        }
+        else if (J.keep_cells) pgm_sweep_chain<R, true>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
         else pgm_sweep_chain<R, false>(J, role, lane, pool, fsync, abort_flag, aborted, spin_limit);
         if (trace && threadIdx.x == 0) trace[6 * it + 2] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();

@@ -190,6 +190,7 @@ struct pgm_align_batch {
     uint32_t nworkers = 0, maxnblk = 0;
     PgmJob *d_jobs = nullptr;
     uint32_t *d_order = nullptr;
+    int *d_tabhdr = nullptr;   // class headers of the lean jobs (PgmJob::tabhdr), PGM_TAB_HDR ints per job of the batch; NULL: no lean job
     size_t in_bytes = 0, work_bytes = 0, cell_bytes = 0, out_bytes = 0;
     std::vector<size_t> res_off, map1_off, map2_off;  // offsets inside d_out
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -467,7 +468,7 @@ static void finalize_side(uint8_t *base, uint32_t n, SideOff &o, int side, bool 
 
 // Device-only regions of one job (offsets inside the batch's work / cell / result / score buffers) and its slice of the
 // progress counters (pass 1 of pgm_align_batch_create).
-struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog, codes, endcell, ltab, lready; uint32_t lrows, lcols; };
+struct JobOff { SideOff s1, s2; size_t M, pi, g1f, a1, t2, aux2, map1, map2, ms, mp, res, cells, tb1, tb2, S, prog, codes, endcell, ltab, lready, cls; uint32_t lrows, lcols; };
 struct BatchLayout { DevLayout W, C, O, SL; size_t sync_ints = 64; };   // sync: [0] abort flag, [1] ticket counter of the band list, [2] of the lean list; on a cache line of their own, [32] pre-link tasks announced, [33] tracebacks finished (polled by every idle worker)
 static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, uint32_t rshift, bool lean, bool keep, JobOff &o) {
     const uint32_t R = 1u << rshift, rows = PGM_ROWS * R;
@@ -487,6 +488,7 @@ static void layout_job(BatchLayout &L, uint32_t n1, uint32_t n2, uint32_t dim, u
     o.cells = L.C.take(keep ? sizeof(float4) * (size_t)nb * tsteps * 64u * R : 16, 1024);   // (a lean job without the test hook: codes only)
     o.codes = L.W.take(lean ? 4 * (size_t)nb * nblk * 64u * R : 16);   // one word per lane, row and block of eight steps
     o.endcell = L.W.take(16, 16);
+    o.cls = L.W.take((lean && !keep) ? (size_t)n1 + n2 : 16, 16);   // classes of the nodes of a lean job (PgmJob::cls1 / cls2)
     o.S = L.SL.take(sizeof(float) * (size_t)nb * nblk * 64u * PGM_BLOCK * R, 1024);
     o.prog = L.sync_ints;
     L.sync_ints += (nb + 3) / 4 * 4;
@@ -629,6 +631,15 @@ static CuShares cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double
     else if (nlean) lean = std::min(nlean, lean + left);
     r.lean = lean; r.band = band; r.rest = rest; r.tb = tb;
     return r;
+}
+
+// classes of the nodes of the lean jobs (PgmJob::cls1): once per batch, behind the upload of the inputs and the job descriptors
+static hipError_t classify_lean_jobs(pgm_ctx *ctx, pgm_align_batch *b) {
+    if (!b->d_tabhdr || b->njobs == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(b->d_tabhdr, 0, 4 * (size_t)PGM_TAB_HDR * b->njobs, ctx->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pgm_classify_kernel, dim3(b->njobs, 2, (b->maxn + 1023) / 1024), dim3(256), 0, ctx->stream, b->d_jobs);
+    return hipGetLastError();
 }
 
 #define PGM_STATUS_PENDING 0x7ffffff0   /* status word of a job's result record in the pinned block until its traceback worker has written it */
@@ -849,6 +860,10 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                  small_order = SM.take(4 * (size_t)std::max(1u, njobs)), small_items = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)),
                  small_lean = SM.take(4 * (size_t)std::max(1u, njobs)), small_tblist = SM.take(8 * (size_t)std::max(1u, njobs)),
                  small_bands = SM.take(sizeof(PgmItem) * std::max<size_t>(1, total_bands)), small_times = SM.take(16 * (size_t)std::max(1u, njobs) + 16);
+    bool any_lean = false;
+    for (uint32_t i = 0; i < njobs; ++i) any_lean = any_lean || (b->jobs[i].lean && !b->jobs[i].keep_cells);
+    if (tools_env("PGM_NO_LEAN_TABLE") || getenv("PGM_X_NO_LEAN_TABLE")) any_lean = false;   // (the second: a release-build switch for tools/ab scripts)
+    const size_t small_tabhdr = SM.take(any_lean ? 4 * (size_t)PGM_TAB_HDR * njobs : 16);
     const size_t small_bytes = SM.bytes;
     std::atomic<int> alloc_state(0);   // 1: the device buffers exist (the flattening threads then upload their jobs' slices), -1: failed
     std::atomic<int> upload_err((int)hipSuccess);
@@ -870,6 +885,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
             b->d_tblist = (int2 *)(b->d_small + small_tblist);
             b->d_bands = (PgmItem *)(b->d_small + small_bands);
             b->d_times = (unsigned long long *)(b->d_small + small_times);
+            b->d_tabhdr = any_lean ? (int *)(b->d_small + small_tabhdr) : nullptr;
         }
         alloc_err = e2;
         alloc_state.store(e2 == hipSuccess ? 1 : -1, std::memory_order_release);
@@ -1061,6 +1077,8 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         J.cells = (float4 *)(b->d_cells + o.cells);
         J.codes = (uint32_t *)(w + o.codes);
         J.endcell = (float4 *)(w + o.endcell);
+        if (J.lean && !J.keep_cells && b->d_tabhdr) { J.cls1 = w + o.cls; J.cls2 = w + o.cls + J.n1; J.tabhdr = b->d_tabhdr + (size_t)PGM_TAB_HDR * i; }
+        else { J.cls1 = nullptr; J.cls2 = nullptr; J.tabhdr = nullptr; }
         J.S = (float *)(b->d_S + o.S);
         J.prog = b->d_sync + o.prog;
         J.ltab = (uint16_t *)(w + o.ltab); J.lready = b->d_sync + o.lready; J.lrows = o.lrows; J.lcols = o.lcols;
@@ -1323,6 +1341,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         (e = hipMemcpyAsync(b->d_items, items.data(), sizeof(PgmItem) * items.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_lean, lean_list.data(), 4 * lean_list.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
         (e = hipMemcpyAsync(b->d_bands, bands.data(), sizeof(PgmItem) * bands.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = classify_lean_jobs(ctx, b)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
         pgm_align_batch_destroy(ctx, b);
         return fail(PGM_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(e));

@@ -142,6 +142,13 @@ struct PgmJob {
     // (R rows per lane: S[(((b * nblk + (t >> 3)) * R + r) * 64 + lane) * 8 + (t & 7)])
     float *S;
     uint32_t nblk;         // ceil(tsteps / 8)
+    // Chain-only jobs of two SEQUENCE graphs — every profile column one-hot, uniform (1 / dim) or empty — need no score matrix: S(y, x)
+    // depends on the classes of row y and column x alone, a (dim + 2)^2 table that pgm_lean_kernel builds per job from one node of
+    // every class.  cls1 / cls2: class of every node (0 .. dim-1 the symbol, dim uniform, dim + 1 empty, 255 none of these; written
+    // once per batch by pgm_classify_kernel); tabhdr[0] != 0: some node has no class (scores through S as for every other job),
+    // tabhdr[1 + c] / tabhdr[1 + dim + 2 + c]: a node of class c of graph 1 / 2, plus one (0: the class is empty).  NULL: not a lean job.
+    const uint8_t *cls1, *cls2;
+    int *tabhdr;
 
     // lean jobs: the traceback's decisions, four bits per cell (see pgm_sweep_chain), [nb][nblk][R][64] words of eight
     // steps; the END node's predecessor cell (n1-2, n2-2) {M, X, W, Y}; whether the four matrices are written to `cells` at all
