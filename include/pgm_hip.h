@@ -110,7 +110,10 @@ int pgm_align_batch_create(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const 
 /* The same with flags.  PGM_BATCH_KEEP_MATRICES: every job's M, X, Y, W matrices are written to device memory so that
  * pgm_align_batch_read_matrices can return them (test hook).  Without it a job of two plain chains (sequence graph against
  * sequence graph) keeps one decision byte per cell instead of the 16 bytes of the four floats: its traceback walks the
- * decisions the fill took with the operands in registers (same tie rules, GraphAlign.h:382-411), the mappings are the same. */
+ * decisions the fill took with the operands in registers (same tie rules, GraphAlign.h:382-411), the mappings are the same.
+ * If, in addition, every profile column of both graphs is one-hot, uniform (1 / dim) or empty — the leaf level of a guide tree —
+ * the emission scores (GraphAlign.h:146-163) are not stored either: S(y, x) depends on the classes of row y and column x alone,
+ * a (dim + 2)^2 table per job (same operations on the same operands as for any other cell: bit-identical scores). */
 #define PGM_BATCH_KEEP_MATRICES 1u
 int pgm_align_batch_create_ex(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *const *g1,
                               const pgm_graph *const *g2, const pgm_model *const *model,
@@ -166,7 +169,8 @@ int pgm_test_cu_shares(uint32_t cus, double lean_cost, uint32_t nlean, double ba
 /* Test hook: copy one job's DP matrices back as the reference lays them out (n1 x n2,
  * column-major, element (y,x) at y + x*n1).  Only rows < n1-1 and columns < n2-1 are
  * defined (the END row/column are never written by the reference's fill either).
- * Any of M,X,Y,W may be NULL.  S is the emission matrix of GraphAlign.h:146-163. */
+ * Any of M,X,Y,W may be NULL.  S is the emission matrix of GraphAlign.h:146-163 (PGM_ERR_INVALID for a job of two sequence graphs
+ * in a batch without PGM_BATCH_KEEP_MATRICES: its scores were never stored). */
 int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job, float *M,
                                   float *X, float *Y, float *W, float *S);
 

@@ -1615,6 +1615,11 @@ int pgm_align_batch_read_matrices(pgm_ctx *ctx, pgm_align_batch *b, uint32_t job
     const size_t N = (size_t)J.n1 * J.n2;
     if ((M || X || Y || W) && !J.keep_cells)
         return fail(PGM_ERR_INVALID, "the DP matrices of a chain-only job are only kept for a batch created with PGM_BATCH_KEEP_MATRICES");
+    if (S && J.tabhdr) {   // (a job of two sequence graphs looks its scores up in a class table: nothing was written to S)
+        int bad = 1;
+        HIPCHK(hipMemcpy(&bad, J.tabhdr, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad == 0) return fail(PGM_ERR_INVALID, "the score matrix of a job of two sequence graphs is only stored for a batch created with PGM_BATCH_KEEP_MATRICES");
+    }
     if (M || X || Y || W) {
         const uint32_t sh = J.rshift, R = 1u << sh;
         const size_t ncell = (size_t)J.nb * J.tsteps * 64u * R;
