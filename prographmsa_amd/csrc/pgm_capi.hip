@@ -690,22 +690,27 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
     if (fork && (e = hipStreamWaitEvent(ctx->stream2, b->ev_fork, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(ctx->stream3, b->ev_fork, 0)) != hipSuccess) return e;
     const uint32_t nrest = b->nitems - b->ncrit;
+    // The launch of the longest chains goes out on the PRIMARY stream, right behind the emission kernel; the main launch on stream4, behind
+    // the fork event like the lean and band kernels (a kernel behind an event of another stream starts 50-60 us later: measured on the
+    // root of the headline batch, whose traceback is the last thing the stage waits for, when it was the other way round).
+    const bool swap_streams = critk && !tools_env("PGM_C3_DBG");
+    hipStream_t sc = swap_streams ? s : ctx->stream4, sr = swap_streams ? ctx->stream4 : s;
 #ifdef PGM_TOOLS
     if (tools_env("PGM_C3_DBG") && !b->d_c3dbg && b->nitems && hipMalloc((void **)&b->d_c3dbg, 512 * (size_t)b->nitems) != hipSuccess) b->d_c3dbg = nullptr;
     if (b->d_c3dbg) (void)hipMemsetAsync(b->d_c3dbg, 0, 512 * (size_t)b->nitems, s);
-    if (critk && b->crit_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, b->d_c3dbg, tbq);
+    if (critk && b->crit_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, sc, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, b->d_c3dbg, tbq);
     else
 #endif
-    if (critk && b->crit_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, (unsigned long long *)nullptr, tbq);
-    else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET, tbq);
+    if (critk && b->crit_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_C3_WAVES), 0, sc, b->d_jobs, b->d_items, b->ncrit, b->d_sync, spin_limit, stall_job, stall_band, (uint32_t)PGM_SY_CRIT_TICKET, (unsigned long long *)nullptr, tbq);
+    else if (critk) hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, sc, b->d_jobs, b->d_items, b->ncrit, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, (uint32_t)PGM_SY_CRIT_TICKET, tbq);
     if (nrest == 0) {}   // (no job for this launch)
 #ifdef PGM_TOOLS
-    else if (b->rest_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, b->d_c3dbg + 64 * (size_t)b->ncrit, tbq);
+    else if (b->rest_c3 && b->d_c3dbg) hipLaunchKernelGGL((pgm_crit_kernel<true>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, sr, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, b->d_c3dbg + 64 * (size_t)b->ncrit, tbq);
 #endif
-    else if (b->rest_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, (unsigned long long *)nullptr, tbq);
-    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
-    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
-    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
+    else if (b->rest_c3) hipLaunchKernelGGL((pgm_crit_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_C3_WAVES), 0, sr, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, spin_limit, stall_job, stall_band, 1u, (unsigned long long *)nullptr, tbq);
+    else if (dbgv == 8) hipLaunchKernelGGL((pgm_fill_kernel<true, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
+    else if (b->d_trace || dbg_flags) hipLaunchKernelGGL((pgm_fill_kernel<false, true>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
+    else hipLaunchKernelGGL((pgm_fill_kernel<false, false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_items + b->ncrit, nrest, b->d_sync, b->d_trace, spin_limit, stall_job, stall_band, dbg_flags, 1u, tbq);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (fork) {
         // the lean jobs' kernel, launched after the fill kernel (whose grid leaves nlean_workers CUs free)
@@ -731,20 +736,20 @@ static hipError_t launch_all(pgm_ctx *ctx, pgm_align_batch *b, bool timed) {
         if ((e = hipEventRecord(b->ev_join_b, ctx->stream3)) != hipSuccess) return e;
     }
     if (critk) {
-        if (beside) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
-        else if (tbk && b->ntb_c) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, ctx->stream4, b->d_jobs, b->d_tblist + b->ntb, b->ntb_c, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off + 2 * njp, 16u, 0u, 1u);
+        if (beside) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, sc, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        else if (tbk && b->ntb_c) hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ncrit_workers), dim3(64 * PGM_WAVES), 0, sc, b->d_jobs, b->d_tblist + b->ntb, b->ntb_c, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off + 2 * njp, 16u, 0u, 1u);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipEventRecord(b->ev_join_c, ctx->stream4)) != hipSuccess) return e;
     }
     if (beside && nrest != 0) {
-        hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
+        hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->nworkers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_tblist, ntb_all, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, tbq, 1u);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     } else if (!beside && tbk && b->ntb) {
         // the tracebacks of the fill kernel's jobs, behind it on its stream
-        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
-        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, s, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
+        if (b->d_trace) hipLaunchKernelGGL((pgm_tb_kernel<true>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
+        else hipLaunchKernelGGL((pgm_tb_kernel<false>), dim3(b->ntb_workers), dim3(64 * PGM_WAVES), 0, sr, b->d_jobs, b->d_tblist, b->ntb, b->d_sync, b->d_trace, b->test_spin_limit, b->lq_off, 0u, 0u, 1u);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (critk && (e = hipEventRecord(b->ev_join_c, ctx->stream4)) != hipSuccess) return e;   // (behind whatever went to stream4)
     if (beside && (e = hipStreamWaitEvent(s, b->ev_join_t, 0)) != hipSuccess) return e;
     if (bandk && (e = hipStreamWaitEvent(s, b->ev_join_b, 0)) != hipSuccess) return e;
     if (critk && (e = hipStreamWaitEvent(s, b->ev_join_c, 0)) != hipSuccess) return e;
