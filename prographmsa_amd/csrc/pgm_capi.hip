@@ -1289,6 +1289,14 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         }
         b->nwide_workers = wide_cus;
         b->nband_workers = band_cus;
+        if (total_c != 0) {
+            // the launch of the longest chains has a worker per band — but a job never has more than tsteps / lag + 2 of its bands under way
+            // at the same time (the first are through before the last may start): the workers beyond that go to the main launch
+            uint32_t need = 0;
+            for (uint32_t i = 0; i < njobs; ++i)
+                if (!per_job_c[i].empty()) need += std::min<uint32_t>(b->jobs[i].nb, b->jobs[i].tsteps / (uint32_t)std::max(1.0, lag) + 2u);
+            crit_cus = std::max(1u, std::min(crit_cus, need));
+        }
         capacity = std::max(1u, capacity > lean_cus + band_cus + crit_cus + sh.tb ? capacity - lean_cus - band_cus - crit_cus - sh.tb : 1u);   // the main launch's CUs
         b->ncrit_workers = crit_cus;
         std::vector<PgmItem> items_rest;
