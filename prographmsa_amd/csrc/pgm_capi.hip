@@ -308,10 +308,15 @@ static int flatten_side(const pgm_graph *g, const pgm_scores &sc, Arena &A, Side
     const uint32_t n = g->n;
     const bool resident = res && res->dev_sites;
     if (n < 2 || (!g->sites && !resident) || !g->e_rowptr) return PGM_ERR_INVALID;
-    std::vector<float> xv, pv;
-    std::vector<int32_t> xp(n + 1, 0), pp(n + 1, 0);
-    std::vector<uint32_t> xc, pc, pu;
-    std::vector<PgmNode2> ni(n);
+    // (scratch of the calling pool thread, kept between jobs: sixteen threads allocating and freeing ~150 KB per side
+    // contend for the address space with the allocation thread's hipMalloc)
+    static thread_local std::vector<float> xv, pv;
+    static thread_local std::vector<int32_t> xp, pp;
+    static thread_local std::vector<uint32_t> xc, pc, pu;
+    static thread_local std::vector<PgmNode2> ni;
+    xv.clear(); pv.clear(); xc.clear(); pc.clear(); pu.clear();
+    xp.assign(n + 1, 0); pp.assign(n + 1, 0);
+    ni.resize(n);
     o.nodes_with_extras = 0; o.has_long = 0; o.maxd_cap = 1; o.maxd_kf8 = 1; o.nkill = 0;
     o.cp.assign(n + 1, 0); o.cd.clear(); o.cv.clear();
     for (uint32_t v = 0; v < n; ++v) {
@@ -856,7 +861,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     const bool cprof = getenv("PGM_HOST_PROFILE") != nullptr;   // tools: where the time of create goes
     auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tc0 = now_ms();
-    double tc_alloc = 0, tc_hostalloc = 0;
+    double tc_alloc = 0, tc_hostalloc = 0, tc_slot[6] = {0, 0, 0, 0, 0, 0};
     // one small allocation: progress counters, job descriptors, size order, work list (at most one item per band)
     size_t total_bands = 0;
     for (uint32_t i = 0; i < njobs; ++i) total_bands += b->jobs[i].nb;
@@ -875,12 +880,14 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     std::thread alloc_thread([&]() {
         const double ta0 = now_ms();
         hipError_t e2 = hipSetDevice(ctx->device);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN]);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK]);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS]);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT]);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S]);
-        if (e2 == hipSuccess) e2 = cache_take(ctx, pgm_ctx::C_SMALL, small_bytes, (void **)&b->d_small, &b->cap[pgm_ctx::C_SMALL]);
+        double tprev = ta0;
+        auto lap = [&](int k) { const double t = now_ms(); tc_slot[k] = t - tprev; tprev = t; };
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_IN, b->in_bytes, (void **)&b->d_in, &b->cap[pgm_ctx::C_IN]); lap(0); }
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_WORK, b->work_bytes, (void **)&b->d_work, &b->cap[pgm_ctx::C_WORK]); lap(1); }
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_CELLS, b->cell_bytes, (void **)&b->d_cells, &b->cap[pgm_ctx::C_CELLS]); lap(2); }
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_OUT, b->out_bytes, (void **)&b->d_out, &b->cap[pgm_ctx::C_OUT]); lap(3); }
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_S, b->s_bytes, (void **)&b->d_S, &b->cap[pgm_ctx::C_S]); lap(4); }
+        if (e2 == hipSuccess) { e2 = cache_take(ctx, pgm_ctx::C_SMALL, small_bytes, (void **)&b->d_small, &b->cap[pgm_ctx::C_SMALL]); lap(5); }
         if (e2 == hipSuccess) {
             b->d_sync = (int *)(b->d_small + small_sync);
             b->d_jobs = (PgmJob *)(b->d_small + small_jobs);
@@ -1368,6 +1375,9 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
     if (cprof)
         fprintf(stderr, "    create: sizes %.2f ms, pinned input block %.2f, flatten %.2f, wait for the allocations %.2f (device %.2f, pinned results %.2f), work list %.2f, upload of %.1f MB %.2f\n",
                 tc0 - tcs, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc_alloc, tc_hostalloc, tc4 - tc3, b->in_bytes / 1e6, now_ms() - tc4);
+    if (cprof)
+        fprintf(stderr, "    device buffers: inputs %.1f MB %.2f ms, work %.1f MB %.2f, cells %.1f MB %.2f, results %.1f MB %.2f, S %.1f MB %.2f, small %.2f\n",
+                b->in_bytes / 1e6, tc_slot[0], b->work_bytes / 1e6, tc_slot[1], b->cell_bytes / 1e6, tc_slot[2], b->out_bytes / 1e6, tc_slot[3], b->s_bytes / 1e6, tc_slot[4], tc_slot[5]);
     *out = b;
     return PGM_OK;
 }
