@@ -104,6 +104,36 @@ void Graph::setRepeatsFromMap(const RepeatMap &rep_map) {
     for (index_t i = 0; i < n_; ++i) r_rowptr_[i + 1] += r_rowptr_[i];
 }
 
+void Graph::reset() {   // Graph.h:369-373
+    if (sites_.empty()) error("Graph::reset needs the profiles on the host");
+    std::fill(sites_.begin(), sites_.end(), 1.0);
+    std::fill(sites_.begin(), sites_.begin() + dim_, 0.0);
+    std::fill(sites_.end() - dim_, sites_.end(), 0.0);
+}
+
+void Graph::rmNodes(index_t first, index_t count) {   // Graph.h:375-426
+    if (first < 1 || first + count > n_) error("Graph::rmNodes: range outside the graph");
+    const index_t nn = n_ - count;
+    auto gone = [&](index_t v) { return v >= first && v < first + count; };
+    auto moved = [&](index_t v) { return v >= first ? v - count : v; };
+    std::vector<int32_t> erp(nn + 1, 0), rrp(nn + 1, 0);
+    std::vector<uint32_t> ec, rc, ru;
+    std::vector<float> ev;
+    for (index_t to = 0; to < n_; ++to) {
+        if (gone(to)) continue;
+        for (int32_t e = e_rowptr_[to]; e < e_rowptr_[to + 1]; ++e)
+            if (!gone(e_col_[e])) { ec.push_back(moved(e_col_[e])); ev.push_back(e_val_[e]); }
+        for (int32_t e = r_rowptr_[to]; e < r_rowptr_[to + 1]; ++e)
+            if (!gone(r_col_[e])) { rc.push_back(moved(r_col_[e])); ru.push_back(r_units_[e]); }
+        erp[moved(to) + 1] = (int32_t)ec.size();
+        rrp[moved(to) + 1] = (int32_t)rc.size();
+    }
+    e_rowptr_.swap(erp); e_col_.swap(ec); e_val_.swap(ev);
+    r_rowptr_.swap(rrp); r_col_.swap(rc); r_units_.swap(ru);
+    if (!sites_.empty()) sites_.erase(sites_.begin() + (size_t)dim_ * first, sites_.begin() + (size_t)dim_ * (first + count));
+    n_ = nn;
+}
+
 void Graph::addRepeats(const std::vector<std::vector<int>> &tr_homologies) {
     RepeatMap tredges;
     for (const std::vector<int> &h : tr_homologies) {   // getRepeatEdges (Graph.h:48-79), offset 0

@@ -413,4 +413,92 @@ AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<
     return finishMerge(g1, g2, plan, profiles.data(), support1, support2);
 }
 
+// mergeGraphsIncremental (GraphAlign.h:729-882).  Same walk as planMerge, one model: a node of the ancestral graph keeps its
+// column, a node of `graph` shows P g, a matched pair their element-wise product; every column normalised.  The homologous path is
+// the one of finishMerge; the edges of both graphs are carried over at their own cost (no penalties for unused edges).
+AncestralResult mergeGraphsIncremental(const Graph &anc_graph, const Graph &graph, const std::vector<index_t> &anc_mapping,
+                                       const std::vector<index_t> &mapping, const Model &model) {
+    const int D = anc_graph.dim();
+    const index_t NONE = (index_t)-1;
+    if (anc_mapping.size() != mapping.size()) error("mergeGraphsIncremental: mappings of different lengths");
+    AncestralResult result;
+    std::vector<double> profiles, p, q;
+    auto node = [&](index_t k1, index_t k2, bool matched) {
+        if (k1 != NONE && k2 != NONE) {
+            matvec(model.P, graph.col(k2), D, q);
+            p.assign(anc_graph.col(k1), anc_graph.col(k1) + D);
+            for (int a = 0; a < D; ++a) p[(size_t)a] *= q[(size_t)a];
+        } else if (k1 != NONE) p.assign(anc_graph.col(k1), anc_graph.col(k1) + D);
+        else matvec(model.P, graph.col(k2), D, p);
+        normalize(p);
+        profiles.insert(profiles.end(), p.begin(), p.end());
+        result.mapping1.push_back(k1); result.mapping2.push_back(k2); result.is_matched.push_back(matched);
+    };
+    /* unify graphs (:747-797) */
+    for (index_t i1 = 0, i2 = 0, j = 0; j < anc_mapping.size(); ++j) {
+        const index_t k1 = anc_mapping[j], k2 = mapping[j];
+        if (k1 != NONE) {
+            for (; i1 != k1; ++i1) node(i1, NONE, false);
+            ++i1;
+        }
+        if (k2 != NONE) {
+            for (; i2 != k2; ++i2) node(NONE, i2, false);
+            ++i2;
+        }
+        if (k1 == NONE && k2 == NONE) error("error in mapping");
+        node(k1, k2, true);
+    }
+    const size_t nnodes = result.mapping1.size();
+    std::vector<Graph::EdgeRec> edges;
+    std::vector<Graph::RepeatRec> repeats;
+    auto updateEdge = [&](index_t from, index_t to, dp_score_t cost) { edges.push_back(Graph::EdgeRec{to, from, cost}); };
+    /* homologous path and allow skipping newly inserted gaps (:803-834) */
+    index_t last_xy = 0, last_x = 0, last_y = 0, last_mapped = 0;
+    for (index_t i = 1; i < nnodes; ++i) {
+        if (!result.is_matched[i]) continue;
+        updateEdge(last_mapped, i, (dp_score_t)0);
+        last_mapped = i;
+        if (result.mapping1[i] != NONE && result.mapping2[i] != NONE) {
+            if (last_xy != i - 1) updateEdge(last_xy, i, (dp_score_t)0);
+            last_xy = i;
+        }
+        if (result.mapping1[i] != NONE) {
+            if (last_y != i - 1) updateEdge(last_y, i, (dp_score_t)0);
+            last_y = i;
+        }
+        if (result.mapping2[i] != NONE) {
+            if (last_x != i - 1) updateEdge(last_x, i, (dp_score_t)0);
+            last_x = i;
+        }
+    }
+    /* inverse mappings (:838-851), the edges of both graphs (:855-880) */
+    std::vector<index_t> inv1(anc_graph.size(), 0), inv2(graph.size(), 0);
+    for (index_t i = 0; i < nnodes; ++i) {
+        if (result.mapping1[i] != NONE) inv1[result.mapping1[i]] = i;
+        if (result.mapping2[i] != NONE) inv2[result.mapping2[i]] = i;
+    }
+    for (int side = 0; side < 2; ++side) {
+        const Graph &g = side == 0 ? anc_graph : graph;
+        const std::vector<index_t> &inv = side == 0 ? inv1 : inv2;
+        for (index_t to = 0; to < g.size(); ++to)
+            for (Graph::PredIterator from = g.getPreds(to, 0, 0); from; ++from) {
+                if (!from.isRepeat()) updateEdge(inv[*from], inv[to], from.value());
+                else repeats.push_back(Graph::RepeatRec{inv[to], inv[*from], from.repeatUnits()});
+            }
+    }
+    // (updateEdge, GraphAlign.h:538-547: of two edges with the same ends the cheaper one, of two repeats the one with fewer units)
+    std::sort(edges.begin(), edges.end(), [](const Graph::EdgeRec &a, const Graph::EdgeRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.cost < c.cost); });
+    size_t w = 0;
+    for (size_t k = 0; k < edges.size(); ++k)
+        if (w == 0 || edges[w - 1].to != edges[k].to || edges[w - 1].from != edges[k].from) edges[w++] = edges[k];
+    edges.resize(w);
+    std::sort(repeats.begin(), repeats.end(), [](const Graph::RepeatRec &a, const Graph::RepeatRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.units < c.units); });
+    w = 0;
+    for (size_t k = 0; k < repeats.size(); ++k)
+        if (w == 0 || repeats[w - 1].to != repeats[k].to || repeats[w - 1].from != repeats[k].from) repeats[w++] = repeats[k];
+    repeats.resize(w);
+    result.graph = Graph(D, (index_t)nnodes, profiles.data(), edges, repeats);
+    return result;
+}
+
 }  // namespace pgm

@@ -20,7 +20,8 @@ using namespace pgm;
 static void usage() {
     std::cerr << "USAGE: pgmsa [-f|--fasta] [-t|--tree <newick>] [-o <file>] [-T] [-I] [-a] [-m] [-M]\n"
                  "             [--codon] [-c|--cs_profile <lib>] [-i <iters>] [-g rate] [-e prob] [-E prob]\n"
-                 "             [-s prob] [-A] [--dump_jobs <file>] [--dump_dist <file>] [--stats] <fasta file>\n";
+                 "             [-s prob] [-A] [--early_refinement] [--ancestral_seqs] [--profile_out <file>] [-R] [--read_repeats <file>]\n"
+                 "             [--dump_jobs <file>] [--dump_dist <file>] [--stats] <fasta file>\n";
 }
 
 // The backend (device contexts: the HIP runtime's start-up takes 80-400 ms) is created on a thread of its own while the
@@ -192,6 +193,7 @@ int main(int argc, char **argv) {
             else if (s == "-p" || s == "--min_pdist") cmdlineopts.min_pdist = atof(val().c_str());
             else if (s == "-P" || s == "--max_pdist") cmdlineopts.max_pdist = atof(val().c_str());
             else if (s == "--ancestral_seqs") cmdlineopts.ancestral_flag = true;
+            else if (s == "--early_refinement") cmdlineopts.earlyref_flag = true;
             else if (s == "--profile_out") cmdlineopts.profile_file = val();
             else if (s == "--read_repeats") cmdlineopts.readreps_file = val();
             else if (s == "-R" || s == "--repeats") cmdlineopts.repeats_flag = true;

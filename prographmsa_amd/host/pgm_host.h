@@ -38,6 +38,7 @@ struct cmdlineopts_t {
     bool fasta_flag = false, noforcealign_flag = false, nwdist_flag = false, onlytree_flag = false;
     bool mldist_flag = false, mldist_gap_flag = false, codon_flag = false, inputorder_flag = false;
     bool ancestral_flag = false;
+    bool earlyref_flag = false;       // --early_refinement (ProgressiveAlignment.h:102-110)
     std::string profile_file;   // --profile_out (main.cpp:132)
     std::string readreps_file;  // --read_repeats (main.cpp:108)
     bool repeats_flag = false;  // -R: here only the "TR indels" lines on stderr (T-REKS itself is not run: --read_repeats supplies the repeats)
@@ -183,6 +184,10 @@ public:
     // tandem-repeat edges from the unit homologies of the graph's nodes (Graph.h:48-79, 458-469): tr_homology[i] = column of
     // node i + 1 inside its repeat unit, -1 outside a repeat; replaces the repeat matrix
     void addRepeats(const std::vector<std::vector<int>> &tr_homologies);
+    // early refinement (Graph.h:369-426): every profile column but START / END set to ones; nodes [first, first + count) removed
+    // with every edge that touches them
+    void reset();
+    void rmNodes(index_t first, index_t count = 1);
 private:
     int dim_;
     index_t n_;
@@ -318,6 +323,9 @@ AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &p
 AncestralResult mergeGraphs(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1,
                             const std::vector<index_t> &mapping2, const Model &model1, const Model &model2,
                             double support1, double support2);
+// GraphAlign.h:729-882: the graph of an early refinement grows by one aligned descendant at a time (one model, no penalties)
+AncestralResult mergeGraphsIncremental(const Graph &anc_graph, const Graph &graph, const std::vector<index_t> &anc_mapping,
+                                       const std::vector<index_t> &mapping, const Model &model);
 
 // ---------------------------------------------------------------------------------------
 // PhyTree (PhyTree.h) + newick (newick.cpp)

@@ -243,6 +243,101 @@ static std::vector<int> assign_owners(const std::vector<Node> &nodes, int root, 
     return owner;
 }
 
+// earlyRefinement (ProgressiveAlignment.h:114-243) of the nodes of one level, right after their alignment: the node's graph is
+// aligned once more with the graph of every grandchild (of a leaf child: with the leaf) — the second call site of alignGraphs
+// (:170), on the graphs as they are, not cleaned — and rebuilt from those alignments one descendant at a time
+// (mergeGraphsIncremental); nodes no descendant maps to are dropped.  The 2-4 alignments of a node read only the node's old graph,
+// so the whole level goes to the backend as ONE batch; the merges are per node, in the reference's order.
+static void early_refinement(const Alphabet &a, std::vector<Node> &nodes, const std::vector<int> &level, const ModelFactory &model_factory, bool with_repeats) {
+    const index_t NONE = (index_t)-1;
+    struct Desc { int node; double distance, gap_distance; };
+    std::vector<std::vector<Desc>> desc(level.size());
+    std::vector<Model> models;
+    std::vector<std::pair<size_t, size_t>> job_of;   // (position in the level, descendant)
+    auto is_leaf = [&](int v) { return nodes[(size_t)v].child[0] < 0; };
+    for (size_t k = 0; k < level.size(); ++k) {
+        const Node &nd = nodes[(size_t)level[k]];
+        if (is_leaf(nd.child[0]) && is_leaf(nd.child[1])) continue;   // (:124-125: nothing to refine)
+        for (int i = 0; i < 2; ++i) {
+            const int c = nd.child[i];
+            const PhyTree &ct = *nodes[(size_t)c].tree;
+            if (is_leaf(c)) {
+                desc[k].push_back(Desc{c, nodes[(size_t)c].res.is_csprofile ? 0.0 : ct.getBranchLength(), ct.getBranchLength()});
+            } else {
+                for (int j = 0; j < 2; ++j) {
+                    const int gc = nodes[(size_t)c].child[j];
+                    const double bl = nodes[(size_t)gc].tree->getBranchLength();
+                    desc[k].push_back(Desc{gc, ct.getBranchLength() + (nodes[(size_t)gc].res.is_csprofile ? 0.0 : bl), ct.getBranchLength() + bl});
+                }
+            }
+        }
+        for (size_t i = 0; i < desc[k].size(); ++i) { models.push_back(model_factory.getModel(desc[k][i].distance, desc[k][i].gap_distance)); job_of.emplace_back(k, i); }
+    }
+    if (job_of.empty()) return;
+    std::vector<const Graph *> g1(job_of.size()), g2(job_of.size());
+    std::vector<const Model *> mm(job_of.size());
+    for (size_t q = 0; q < job_of.size(); ++q) {
+        g1[q] = &nodes[(size_t)level[job_of[q].first]].res.graph;
+        g2[q] = &nodes[(size_t)desc[job_of[q].first][job_of[q].second].node].res.graph;
+        mm[q] = &models[q];
+    }
+    std::vector<AlignmentResult> ar = alignGraphsBatch(g1, g2, mm, {}, {});
+    std::vector<size_t> first_job(level.size(), 0);
+    for (size_t q = job_of.size(); q-- > 0;) first_job[job_of[q].first] = q;
+    parallel_for(level.size(), [&](size_t k) {
+        const size_t nres = desc[k].size();
+        if (nres == 0) return;
+        Node &nd = nodes[(size_t)level[k]];
+        const ProgressiveAlignmentResult &old_result = nd.res;
+        Graph anc_graph = old_result.graph;
+        anc_graph.reset();
+        std::vector<index_t> anc_mapping(anc_graph.size());
+        for (index_t i = 0; i < anc_graph.size(); ++i) anc_mapping[i] = i;
+        std::vector<std::vector<index_t>> mappings(nres);
+        for (size_t i = 0; i < nres; ++i) {
+            AlignmentResult &al = ar[first_job[k] + i];
+            const Graph &dg = nodes[(size_t)desc[k][i].node].res.graph;
+            for (index_t &m : al.mapping1) if (m != NONE) m = anc_mapping[m];
+            AncestralResult anc = mergeGraphsIncremental(anc_graph, dg, al.mapping1, al.mapping2, models[first_job[k] + i]);
+            anc_graph = anc.graph;
+            mappings[i] = anc.mapping2;
+            /* the old graph's nodes inside the new ancestral graph, which is a superset (:180-188) */
+            std::vector<index_t> inv(anc_graph.size(), (index_t)-2);
+            for (index_t j = 0; j < anc.mapping1.size(); ++j) if (anc.mapping1[j] != NONE) inv[anc.mapping1[j]] = j;
+            for (index_t &m : anc_mapping) m = inv[m];
+            for (size_t j = 0; j < i; ++j) {   // the earlier descendants' mappings follow (:190-198)
+                std::vector<index_t> nm(anc_graph.size());
+                for (index_t v = 0; v < anc_graph.size(); ++v) nm[v] = anc.mapping1[v] != NONE ? mappings[j][anc.mapping1[v]] : NONE;
+                mappings[j].swap(nm);
+            }
+        }
+        /* remove the nodes no descendant uses (:201-228) */
+        auto used = [&](index_t v) { for (size_t j = 0; j < nres; ++j) if (mappings[j][v] != NONE) return true; return false; };
+        for (index_t i = 0; i < anc_graph.size(); ++i) {
+            if (used(i)) continue;
+            for (index_t j = i + 1; j < anc_graph.size(); ++j)
+                if (used(j)) {
+                    anc_graph.rmNodes(i, j - i);
+                    for (size_t q = 0; q < nres; ++q) mappings[q].erase(mappings[q].begin() + i, mappings[q].begin() + j);
+                    --i;
+                    break;
+                }
+        }
+        ProgressiveAlignmentResult result;
+        result.score = old_result.score;
+        result.is_csprofile = false;
+        result.n_tr_indels = old_result.n_tr_indels;
+        result.graph = anc_graph;
+        for (size_t i = 0; i < nres; ++i) {
+            const ProgressiveAlignmentResult &dr = nodes[(size_t)desc[k][i].node].res;
+            extend_alignment(a, result, mappings[i], dr.aligned_sequences, false);
+            extend_tr_homologies(result, mappings[i], dr.tr_homologies, dr.tr_source);
+        }
+        if (with_repeats) result.graph.addRepeats(result.tr_homologies);
+        nd.res = std::move(result);
+    });
+}
+
 ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::map<std::string, sequence_t> &sequences,
                                                  const PhyTree &tree, const CSProfile *csprofile,
                                                  const ModelFactory &model_factory,
@@ -262,7 +357,8 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
     // A pass whose merged profiles stay on the device (see the level loop) builds its leaf graphs there too: the host keeps
     // their edges only (SequenceGraph's profile matrix is 160 bytes per residue: 41 MB for 256 x 1000, otherwise built here,
     // copied into the staging block and uploaded for the alignments, and once more for the merges)
-    const bool resident_pass = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active();
+    const bool resident_pass = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active() &&
+                               !cmdlineopts.earlyref_flag;   // (the incremental merges of an early refinement read the profiles on the host)
     const bool resident_leaves = resident_pass && !csprofile;
     // where the profiles of every node live (worker = device context): all 0 with one context
     std::vector<int> owner(nodes.size(), 0);
@@ -553,12 +649,15 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             if (cmdlineopts.repeats_flag) nd.tr_note = "TR indels at " + create_ancestral_seq_name(result.aligned_sequences) + ": " + std::to_string(ar[k].n_tr_indels);   // (:470-473)
             if (repeats && !repeats->empty()) result.graph.addRepeats(result.tr_homologies);   // (:468; with no annotation at all the merged graph has no repeat edges either way)
             // children are no longer needed (the reference copies them by value and drops them)
-            r1 = ProgressiveAlignmentResult();
-            r2 = ProgressiveAlignmentResult();
+            if (!cmdlineopts.earlyref_flag) {   // (the reference's alignment_cache, ProgressiveAlignment.h:107-109: the parent's refinement reads them again)
+                r1 = ProgressiveAlignmentResult();
+                r2 = ProgressiveAlignmentResult();
+            }
             p.cg1.reset();
             p.cg2.reset();
             profiles[k] = std::vector<double>();
         });
+        if (cmdlineopts.earlyref_flag) early_refinement(a, nodes, level, model_factory, repeats && !repeats->empty());
         const auto tp3 = std::chrono::steady_clock::now();
         if (getenv("PGM_HOST_PROFILE"))
             fprintf(stderr, "[%.1f ms] level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n",

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import gen  # noqa: E402
 
 ONLY = None
-if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral | repeats | angle)
+if "--only" in sys.argv:   # regenerate one section only (nw_trees | full_size | ancestral | repeats | angle | early)
     i = sys.argv.index("--only")
     ONLY = sys.argv[i + 1]
     del sys.argv[i:i + 2]
@@ -124,6 +124,44 @@ def repeats():
     w("repeats.json", json.dumps(out, indent=0))
 
 
+EARLY_CASES = [   # (name, input, extra arguments in front of --early_refinement; the tree is <input>.tree unless the flow builds its own)
+    ("c1", "c1", ["--fasta", "--tree", "c1.tree"]), ("c1_m", "c1", ["--fasta", "-m", "--tree", "c1.tree"]),
+    ("m1", "m1", ["--fasta", "--tree", "m1.tree"]), ("x1", "x1", ["--fasta", "--tree", "x1.tree"]),
+    ("c1_cs", "c1", ["--fasta", "--tree", "c1.tree", "--cs_profile", "K50.lib"]),
+    ("c1_default_flow", "c1", ["--fasta"]), ("c1_a_flow", "c1", ["--fasta", "-a"]),
+    ("cd1", "cd1", ["--codon", "--fasta", "-t", "cd1.tree"]),
+    ("c2_m", "c2", ["--fasta", "-m", "--tree", "c2.tree"]),
+]
+
+
+def early():
+    """--early_refinement (ProgressiveAlignment.h:102-243): after every internal node with a grandchild the node's graph is
+    aligned again with the graphs of its grandchildren — the second call site of alignGraphs (:170), on graphs that are not
+    cleaned — and rebuilt with mergeGraphsIncremental.  Kept: the FASTA of the committed families with the flag (64 x 400 as md5),
+    whether the flag changes the alignment, and the repeat families with -R --read_repeats --early_refinement."""
+    out = {}
+    for name, inp, args in EARLY_CASES:
+        fa = run(args + ["--early_refinement", inp + ".fa"])
+        plain = run(args + [inp + ".fa"])
+        rec = dict(input=inp + ".fa", args=args, changes_alignment=(fa != plain))
+        if len(fa) > 20000: rec["md5"] = hashlib.md5(fa.encode()).hexdigest()
+        else: rec["out"] = fa
+        out[name] = rec
+    reps = []
+    for (n, L, seed, ae) in REPEAT_CASES[:4]:
+        seqs, trd = gen.gen_repeat_family(n, L, seed, annotate_every=ae)
+        w("rep.fa.tmp", gen.fasta(seqs))
+        w("rep.trd.tmp", trd)
+        tree = run(["-T", "-i", "0", "rep.fa.tmp"])
+        w("rep.tree.tmp", tree)
+        r = subprocess.run([BIN, "--fasta", "-R", "--read_repeats", "rep.trd.tmp", "--early_refinement", "-t", "rep.tree.tmp", "rep.fa.tmp"], check=True, capture_output=True, text=True)
+        reps.append(dict(n=n, L=L, seed=seed, annotate_every=ae, tree=tree, out=r.stdout, tr_lines=[ln for ln in r.stderr.splitlines() if "TR indels" in ln]))
+    for f in ("rep.fa.tmp", "rep.trd.tmp", "rep.tree.tmp"):
+        os.remove(f)
+    out["repeats"] = reps
+    w("early.json", json.dumps(out, indent=0))
+
+
 def angle():
     """The reference's flow WITHOUT -a: initial guide tree from the k-mer angle distances (DistanceFactoryAngle.h:55-131), then the
     usual two rounds of alignment + tree re-estimation and the final alignment.  BASELINE config 2 as worded (`--fasta c2.fa`),
@@ -153,6 +191,8 @@ def main():
         return angle()
     if ONLY == "repeats":
         return repeats()
+    if ONLY == "early":
+        return early()
     if ONLY == "ancestral":
         return ancestral()
     if ONLY == "nw_trees":
@@ -260,6 +300,7 @@ def main():
     ancestral()
     repeats()
     angle()
+    early()
     for f in ("pair.fa.tmp", "pair.tree.tmp"):
         os.remove(f)
     print("golden fixtures regenerated in", HERE)

@@ -197,6 +197,39 @@ def test_tandem_repeat_families(oracle_build, tmp_path):
             assert run_oracle(oracle_build, ["--fasta", "-a", "--read_repeats", str(tmp_path / "r.trd"), str(tmp_path / "r.fa")]) == c["out_default_flow"], c["seed"]
 
 
+def _early_args(rec):
+    """arguments of an early.json record with the files of tests/golden spelled out"""
+    out = []
+    for x in rec["args"]:
+        out.append(os.path.join(GOLD, x) if x.endswith(".tree") or x.endswith(".lib") else x)
+    return out + ["--early_refinement", os.path.join(GOLD, rec["input"])]
+
+
+def test_early_refinement(oracle_build, tmp_path):
+    """--early_refinement (ProgressiveAlignment.h:102-243): the second call site of alignGraphs (:170) — the graph of an internal
+    node against the graphs of its grandchildren, not cleaned — plus mergeGraphsIncremental, Graph::reset / rmNodes: the reference
+    binary's FASTA on the committed families (fixed tree, --mldist, context-specific profiles, both default flows, codons, 64 x 400
+    as md5) and on four repeat families (with their "TR indels" lines)."""
+    cases = json.load(open(os.path.join(GOLD, "early.json")))
+    assert sum(c["changes_alignment"] for k, c in cases.items() if k != "repeats") >= 5
+    for name, c in cases.items():
+        if name == "repeats":
+            continue
+        out = run_oracle(oracle_build, _early_args(c))
+        if "md5" in c:
+            assert hashlib.md5(out.encode()).hexdigest() == c["md5"], name
+        else:
+            assert out == c["out"], name
+    exe = os.path.join(oracle_build, "pgmsa_oracle")
+    for c in cases["repeats"]:
+        seqs, trd = gen.gen_repeat_family(c["n"], c["L"], c["seed"], annotate_every=c["annotate_every"])
+        (tmp_path / "r.fa").write_text(gen.fasta(seqs)); (tmp_path / "r.trd").write_text(trd); (tmp_path / "r.tree").write_text(c["tree"])
+        r = subprocess.run([exe, "--fasta", "-R", "--read_repeats", str(tmp_path / "r.trd"), "--early_refinement", "-t", str(tmp_path / "r.tree"), str(tmp_path / "r.fa")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == c["out"], c["seed"]
+        assert [ln for ln in r.stderr.splitlines() if "TR indels" in ln] == c["tr_lines"], c["seed"]
+
+
 def test_default_flow_without_nwdist(oracle_build, tmp_path):
     """The reference's default flow from sequences alone, WITHOUT -a (initial distances: DistanceFactoryAngle): BASELINE config 1 /
     config 2 inputs as worded (`--fasta c2.fa`), a codon family; the 256 x 1000 family with --mldist behind PGM_SLOW_TESTS."""

@@ -1,7 +1,8 @@
 """Differential campaign (build container only): random families through the reference binary and through the CPU oracle
 driver (oracle/_build/pgmsa_oracle); any FASTA / newick difference is printed.  Used to look for parity gaps beyond the
 committed fixtures (this is how the denominator association of c2.m.out.fa was found).  `--angle`: the guide trees from the
-k-mer angle distances instead (round 4: 23 of 60 differed before the orientation / depth-block / libm findings, none after)."""
+k-mer angle distances instead (round 4: 23 of 60 differed before the orientation / depth-block / libm findings, none after).
+`--early`: every case with --early_refinement (the second call site of alignGraphs, ProgressiveAlignment.h:170)."""
 import os, random, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +12,9 @@ OUR = os.path.join(ROOT, "oracle", "_build", "pgmsa_oracle")
 ANGLE = "--angle" in sys.argv   # the initial guide tree from the sequences alone (k-mer angle distances, BioNJ, midpoint root): -T -i 0
 if ANGLE:
     sys.argv.remove("--angle")
+EARLY = "--early" in sys.argv
+if EARLY:
+    sys.argv.remove("--early")
 tmp = tempfile.mkdtemp()
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -34,7 +38,7 @@ for case in range(ncases):
             bad += 1
             print("case %d DIFFERS: n=%d L=%d sub=%g indel=%g seed=%d codon=%d" % (case, n, L, sub, indel, seed, codon), flush=True)
         continue
-    flags = base + rng.choice([[], ["-m"], ["-m"], ["-M"]] if not codon else [[], ["-m"]])
+    flags = base + rng.choice([[], ["-m"], ["-m"], ["-M"]] if not codon else [[], ["-m"]]) + (["--early_refinement"] if EARLY else [])
     tr = subprocess.run([REF] + base + ["-T", "-i", "0", fa], capture_output=True, text=True)
     if tr.returncode:
         print("case %d: reference tree failed" % case); continue
