@@ -25,11 +25,12 @@ while time.time() < t_end:
     fam = gen.gen_codon(n, L, seed, sub=sub, indel=indel) if codon else gen.gen(n, L, seed, sub=sub, indel=indel)
     fa = os.path.join(tmp, "f.fa"); open(fa, "w").write(gen.fasta(fam))
     if codon:
-        flags = rng.choice([["--codon", "--fasta", "-a", "-i", "0"], ["--codon", "--fasta", "-a"], ["--codon", "-T", "-i", "0"]])
+        flags = rng.choice([["--codon", "--fasta", "-a", "-i", "0"], ["--codon", "--fasta", "-a"], ["--codon", "-T", "-i", "0"], ["--codon", "--fasta", "-a", "--early_refinement", "-i", "0"]])
     else:
         flags = rng.choice([["--fasta", "-a"], ["--fasta", "-a", "-m"], ["--fasta", "-a", "-M", "-i", "0"], ["--fasta", "-a", "-i", "1"],
                             ["--fasta", "-a", "--cs_profile", K50, "-i", "0"], ["-a", "-m", "-T", "-i", "0"],
-                            ["--fasta"], ["-T", "-i", "0"]])   # (the last two: the default flow without -a — k-mer angle distances)
+                            ["--fasta"], ["-T", "-i", "0"],    # (these two: the default flow without -a — k-mer angle distances)
+                            ["--fasta", "-a", "--early_refinement", "-i", "0"], ["--fasta", "--early_refinement"]])   # (alignGraphs' second call site: graphs that are not cleaned)
     key = " ".join(f for f in flags if f != K50)
     a = subprocess.run([pg.PGMSA_PATH] + flags + [fa], capture_output=True, text=True)
     b = subprocess.run([ORACLE] + flags + [fa], capture_output=True, text=True)
