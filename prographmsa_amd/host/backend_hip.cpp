@@ -56,7 +56,7 @@ struct HipBackend : Backend {
     }
     // resident profiles (PGM_NO_RESIDENT switches them off): with several contexts the pass is sharded by subtree and the few matrices
     // a parent needs from another device are copied over (progressive.cpp assign_owners, resident_import)
-    bool resident() const override { return !getenv("PGM_NO_RESIDENT"); }
+    bool resident() const override { return !host_switches().no_resident; }
     const double *resident_import(int dst, int src, const double *p, size_t count) override {
         const double *out = nullptr;
         int rc = pgm_resident_import(ctx_of(dst), ctx_of(src), p, (uint64_t)count, &out);

@@ -131,7 +131,7 @@ void DistanceFactoryML::computeDistances(const int32_t *counts, const uint32_t *
     Backend &be = default_backend();
     auto t1 = std::chrono::steady_clock::now();
     bool done = false;
-    if (getenv("PGM_DEVICE_MLDIST") && model_factory->has_eigen() && D <= 20 && np) {
+    if (host_switches().device_mldist && model_factory->has_eigen() && D <= 20 && np) {
         // the whole batch in one kernel (one wavefront per pair); same arithmetic as computeDistance below except for the
         // device library's exp / log (last-bit differences: see csrc/pgm_dist_kernels.h)
         double DIST_MAX, VAR_MAX, VAR_MIN;
@@ -451,7 +451,7 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     std::vector<uint32_t> gaps(np, 0);
     Backend &be = default_backend();
     bool done = false;
-    if (!getenv("PGM_HOST_COUNTS") && np) {
+    if (!host_switches().host_counts && np) {
         // the N^2 L column scan on the device (integer counts, bit-exact: on by default, unlike the ML estimates that follow):
         // value() per residue, -1 for a gap, -2 for a residue without a value
         auto t0 = std::chrono::steady_clock::now();
@@ -518,7 +518,7 @@ DistanceMatrix DistanceFactoryPrealigned::computePwDistances(const std::map<std:
     std::vector<double> seqlen(np, ((double)L + (double)L) / 2.0);
     const auto tq0 = std::chrono::steady_clock::now();
     computeDistances(counts.data(), gaps.data(), seqlen, pi, pj, distances);
-    if (getenv("PGM_HOST_PROFILE"))
+    if (host_switches().profile)
         fprintf(stderr, "  prealigned distances: pair counts %s, estimates %.1f ms\n", done ? "on the device" : "on the host",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
     dump_distances(distances);
@@ -591,7 +591,7 @@ PhyTree *TreeNJ(const Alphabet &a, const std::map<std::string, sequence_t> &seqs
         for (int i = 0; i < dist.dim; ++i) { dist.D(i, i) = 0; dist.V(i, i) = 0; }
         const auto tq1 = std::chrono::steady_clock::now();
         PhyTree *t = midpointRoot(buildNJTree(order, dist));
-        if (getenv("PGM_HOST_PROFILE"))
+        if (host_switches().profile)
             fprintf(stderr, "  TreeNJ: distances %.1f ms, BioNJ + rooting %.1f ms\n", std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
         return t;

@@ -6,6 +6,8 @@
 // (csrc/pgm_merge_kernels.h), the edge bookkeeping here is the reference's.
 #include "pgm_host.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -87,6 +89,25 @@ pgm_scores DynProgScores(const Graph &g1, const Graph &g2, const Model &model) {
 // Job dump: a flat binary record per alignGraphs call so that tests and bench.py can replay the
 // exact jobs of a progressive pass through the C ABI (format documented in prographmsa_amd/jobs.py).
 static std::string g_dump_path;
+const HostSwitches &host_switches() {
+    static const HostSwitches sw = []() {
+        HostSwitches h;
+        h.profile = getenv("PGM_HOST_PROFILE") != nullptr;
+        h.host_merge = getenv("PGM_HOST_MERGE") != nullptr;
+        h.no_resident = getenv("PGM_NO_RESIDENT") != nullptr;
+        h.host_counts = getenv("PGM_HOST_COUNTS") != nullptr;
+        h.device_mldist = getenv("PGM_DEVICE_MLDIST") != nullptr;
+        return h;
+    }();
+    return sw;
+}
+std::string HostSwitches::describe() const {
+    std::string s;
+    auto add = [&](bool on, const char *name) { if (on) { if (!s.empty()) s += ","; s += name; } };
+    add(host_merge, "PGM_HOST_MERGE"); add(no_resident, "PGM_NO_RESIDENT"); add(host_counts, "PGM_HOST_COUNTS"); add(device_mldist, "PGM_DEVICE_MLDIST");
+    return s;
+}
+
 void set_job_dump(const std::string &path) {
     g_dump_path = path;
     if (!path.empty()) { FILE *f = fopen(path.c_str(), "wb"); if (f) fclose(f); }

@@ -86,7 +86,7 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
     g_startup.wait();
     default_backend();
     const double t_init = g_startup.seconds > 0 ? g_startup.seconds : std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("PGM_HOST_PROFILE"))
+    if (host_switches().profile)
         fprintf(stderr, "backend start-up %.1f ms, of which %.1f ms waited for after the set-up\n", t_init * 1e3,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     std::map<std::string, std::vector<repeat_t>> reps;   // main.cpp:367-370 (detection by T-REKS itself is not built here: --read_repeats only)
@@ -113,11 +113,11 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         delete tree;
         const auto tt0 = std::chrono::steady_clock::now();
         tree = TreeNJ(a, result.aligned_sequences, model_factory.get(), true);
-        if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "guide tree from the alignment: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count());
+        if (host_switches().profile) fprintf(stderr, "guide tree from the alignment: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count());
         old_result = result;
     }
     if (!cmdlineopts.onlytree_flag) result = progressive_alignment(a, seqs2, *tree, csprofile.get(), *model_factory, &reps);
-    if (getenv("PGM_HOST_PROFILE")) fprintf(stderr, "[%.1f ms] back in main\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (host_switches().profile) fprintf(stderr, "[%.1f ms] back in main\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     double t_prog = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     out_tree = tree;
 
@@ -147,9 +147,9 @@ static int doAlign(const Alphabet &a, const std::map<std::string, std::string> &
         Backend &be = default_backend();
         fprintf(stderr,
                 "{\"backend\": \"%s\", \"init_s\": %.6f, \"tree_s\": %.6f, \"progressive_s\": %.6f, \"align_cells\": %llu, \"align_s\": %.6f, "
-                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"merge_profiles_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d, \"farm_level_workers\": %d, \"farm_leaf_workers\": %d, \"resident\": %s, \"resident_imports\": %d}\n",
+                "\"nw_cells\": %llu, \"nw_s\": %.6f, \"mldist_s\": %.6f, \"merge_profiles_s\": %.6f, \"farm_workers\": %d, \"farm_tiles\": %d, \"farm_level_workers\": %d, \"farm_leaf_workers\": %d, \"resident\": %s, \"resident_imports\": %d, \"switches\": \"%s\"}\n",
                 be.name(), t_init, t_tree, t_prog, (unsigned long long)be.cells_aligned, be.seconds_align,
-                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.seconds_merge_profiles, be.farm_workers, be.farm_tiles, be.farm_level_workers, be.farm_leaf_workers, be.resident_pass ? "true" : "false", be.resident_imports);
+                (unsigned long long)be.cells_nw, be.seconds_nw, be.seconds_mldist, be.seconds_merge_profiles, be.farm_workers, be.farm_tiles, be.farm_level_workers, be.farm_leaf_workers, be.resident_pass ? "true" : "false", be.resident_imports, host_switches().describe().c_str());
     }
     return 0;
 }
@@ -239,7 +239,7 @@ int main(int argc, char **argv) {
             *out << tree->formatNewick() << std::endl;
         }
         delete tree;
-        if (getenv("PGM_HOST_PROFILE"))
+        if (host_switches().profile)
             fprintf(stderr, "main: output written %.1f ms after its start\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_main).count());
         // The output is complete.  Releasing the contexts' gigabytes of device memory and pinned blocks and shutting the HIP runtime
         // down in an orderly way takes 30-70 ms that the kernel driver spends anyway when the process is gone: leave directly

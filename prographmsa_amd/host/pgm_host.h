@@ -234,6 +234,18 @@ struct AncestralResult {   // GraphAlign.h:14-20
 double averageAlignmentLength(const Graph &g);                                        // :82-96
 pgm_scores DynProgScores(const Graph &g1, const Graph &g2, const Model &model);       // :98-143
 
+// Environment switches of the host side, read ONCE per process (host_switches()): which path runs is decided at start-up and shown by
+// `pgmsa --stats` ("switches"), not re-read per pass.  All of them are test / measurement aids; the defaults are the product.
+struct HostSwitches {
+    bool profile = false;        // PGM_HOST_PROFILE: per-stage timings on stderr
+    bool host_merge = false;     // PGM_HOST_MERGE: the node profiles of mergeGraphs on the host instead of pgm_merge_profiles_batch (same bits)
+    bool no_resident = false;    // PGM_NO_RESIDENT: merged profiles travel through the host between the levels
+    bool host_counts = false;    // PGM_HOST_COUNTS: pair counts of an alignment on the host instead of pgm_prealigned_counts (same integers)
+    bool device_mldist = false;  // PGM_DEVICE_MLDIST: ML distances by pgm_mldist_batch (last-bit differences to the host's estimator)
+    std::string describe() const;   // the switches that are on, comma separated ("" = the product's defaults)
+};
+const HostSwitches &host_switches();
+
 // Backend = the C ABI entry points of include/pgm_hip.h behind a context.  The product binds
 // them to libpgm_hip.so (HIP kernels); tests bind the oracle.  There is no CPU fallback: when
 // the HIP library cannot create a context this throws.

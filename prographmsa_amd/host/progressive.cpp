@@ -357,7 +357,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
     // A pass whose merged profiles stay on the device (see the level loop) builds its leaf graphs there too: the host keeps
     // their edges only (SequenceGraph's profile matrix is 160 bytes per residue: 41 MB for 256 x 1000, otherwise built here,
     // copied into the staging block and uploaded for the alignments, and once more for the merges)
-    const bool resident_pass = default_backend().resident() && !getenv("PGM_HOST_MERGE") && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active() &&
+    const bool resident_pass = default_backend().resident() && !host_switches().host_merge && cmdlineopts.profile_file.empty() && !cmdlineopts.ancestral_flag && !job_dump_active() &&
                                !cmdlineopts.earlyref_flag;   // (the incremental merges of an early refinement read the profiles on the host)
     const bool resident_leaves = resident_pass && !csprofile;
     // where the profiles of every node live (worker = device context): all 0 with one context
@@ -487,7 +487,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             nd.res.graph.addRepeats(nd.res.tr_homologies);
         }
     }
-    if (getenv("PGM_HOST_PROFILE"))
+    if (host_switches().profile)
         fprintf(stderr, "leaves: %zu, %.1f ms (names / owners %.2f, graphs %.2f, profiles %.2f)\n", leaves.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count(),
                 std::chrono::duration<double, std::milli>(tl1 - tl0).count(), std::chrono::duration<double, std::milli>(tl2 - tl1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl2).count());
     // ---- internal nodes, one guide-tree level per batch (ProgressiveAlignment.h:413-476) ----
@@ -565,7 +565,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         });
         const auto tq0 = std::chrono::steady_clock::now();
         bool on_device = false;
-        if (!getenv("PGM_HOST_MERGE")) {
+        if (!host_switches().host_merge) {
             std::vector<pgm_merge_job> mj(L);
             for (size_t k = 0; k < L; ++k) {
                 Node &nd = nodes[level[k]];
@@ -659,7 +659,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         });
         if (cmdlineopts.earlyref_flag) early_refinement(a, nodes, level, model_factory, repeats && !repeats->empty());
         const auto tp3 = std::chrono::steady_clock::now();
-        if (getenv("PGM_HOST_PROFILE"))
+        if (host_switches().profile)
             fprintf(stderr, "[%.1f ms] level %d: %zu nodes, host pre %.1f ms, alignGraphsBatch %.1f ms, host post (merge, extend) %.1f ms\n",
                     std::chrono::duration<double, std::milli>(tp3 - tl0).count(), h, L,
                     std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count(),
@@ -670,10 +670,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
     if (cmdlineopts.repeats_flag)   // the reference prints them as its recursion returns: post-order, which is the order of `nodes`
         for (const Node &nd : nodes) if (!nd.tr_note.empty()) std::cerr << nd.tr_note << std::endl;
     ProgressiveAlignmentResult out = std::move(nodes[root].res);
-    if (getenv("PGM_HOST_PROFILE"))
+    if (host_switches().profile)
         fprintf(stderr, "[%.1f ms] root result taken\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     nodes.clear();
-    if (getenv("PGM_HOST_PROFILE"))
+    if (host_switches().profile)
         fprintf(stderr, "[%.1f ms] nodes released\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count());
     return out;
 }
