@@ -217,6 +217,7 @@ int main(int argc, char **argv) {
         if (!dist_dump.empty()) set_dist_dump(dist_dump);
 
         g_startup.start();
+        parallel_for(64, [](size_t) {});   // (the driver's host threads start while the device runtime does)
         std::vector<std::string> input_order;
         std::map<std::string, std::string> seqs = read_fasta(cmdlineopts.sequence_file, input_order);
         std::ofstream custom_out;
