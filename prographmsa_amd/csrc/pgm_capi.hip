@@ -944,6 +944,18 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
         double longest_crit_chain = 0.0;
         for (uint32_t i = 0; i < njobs; ++i)
             longest_crit_chain = std::max(longest_crit_chain, ((double)((g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS - 1) * 80.0 + (double)(g2[i]->n - 1 + 63)) * 0.42);
+        // A batch that would not fill the device as MODE 2 sweeps (one band per CU: 0.42 us per step of every band) — a guide-tree level of
+        // 16 or 32 jobs on its own, not the 255 jobs of a whole pass — is bound by its longest chain of sweeps, and that chain is 2-3 x
+        // shorter in pgm_crit_kernel than on a wavefront of pgm_band_kernel: every job of 8 bands or more goes there then (levels 3 and 4
+        // of the headline family alone: 2.05 -> 1.56 and 2.29 -> 1.40 ms per call; level 2, 64 jobs, would fill the device 1.6 times over
+        // and stays: 2.2 against 2.4 ms).
+        uint32_t promote_bands = 0xffffffffu;
+        if (!tools_env("PGM_MODE2_BANDS") && !tools_env("PGM_NO_PROMOTE")) {
+            double crit_load = 0.0;
+            for (uint32_t i = 0; i < njobs; ++i)
+                if (!b->jobs[i].lean) crit_load += (double)((g1[i]->n - 1 + PGM_ROWS - 1) / PGM_ROWS) * (double)(g2[i]->n - 1 + 63) * 0.42;
+            if (crit_load <= 1.25 * (double)ctx->prop.multiProcessorCount * longest_crit_chain) promote_bands = 8u;
+        }
         const uint32_t chunk_jobs = (uint32_t)std::max<size_t>(1, ((size_t)8 << 20) / std::max<size_t>(1, in_base[njobs] / std::max(1u, njobs)));
         std::vector<std::atomic<uint32_t>> chunk_done((njobs + chunk_jobs - 1) / chunk_jobs + 1);
         for (auto &cd : chunk_done) cd.store(0);
@@ -979,7 +991,7 @@ int pgm_align_batch_create_res(pgm_ctx *ctx, uint32_t njobs, const pgm_graph *co
                 const double far_density = 0.5 * ((double)o.s1.cp[g1[i]->n] / g1[i]->n + (double)o.s2.cp[g2[i]->n] / g2[i]->n);
                 const double chain_wide = ((double)(nb_job - 1) * 78.0 + (double)(g2[i]->n - 1 + 63)) * (0.7 + 10.0 * far_density);
                 const bool fits_wide = slot1 <= (uint32_t)(PGM_POOL / PGM_WIDE_WAVES / 16 * 16) && chain_wide <= 0.9 * longest_crit_chain && !tools_env("PGM_NO_WIDE");
-                J.mode2 = (J.has_extras && ((hD >= mode2_min_hd && !fits_wide) || nb_job >= (uint32_t)mode2_min_bands || has_long) && !no_helper) ? 1u : 0u;
+                J.mode2 = (J.has_extras && ((hD >= mode2_min_hd && !fits_wide) || nb_job >= (uint32_t)mode2_min_bands || nb_job >= promote_bands || has_long) && !no_helper) ? 1u : 0u;
                 if (J.mode2) {   // (a MODE 2 sweep keeps every on-chip distance of the graphs, whatever the number of entries of a node)
                     while (hD < o.s1.maxd_cap + o.s2.maxd_cap + (uint32_t)PGM_BLOCK) hD *= 2;
                     while (hDX < o.s2.maxd_cap + 1) hDX *= 2;

@@ -114,6 +114,29 @@ def test_critical_path_kernel_and_wide_bands_bit_exact(ctx):
         b.close()
 
 
+def test_job_modes_of_small_and_large_batches_bit_exact(ctx):
+    """A batch that would not fill the device as MODE 2 sweeps sends every job of 8 bands or more to the critical-path kernel
+    (pgm_align_batch_create: a guide-tree level on its own); the same jobs among enough others stay on the band kernel's wavefronts.
+    Both ways: all four DP matrices, scores and mappings of those jobs against the oracle, and the fillers' mappings."""
+    from prographmsa_amd import jobs as J
+    import oracle_lib
+    probes = [J.random_job(8100, 700, 650, skip_frac=0.2, skip_span=20, skip_max=2, drop_chain_frac=0.0),
+              J.random_job(8101, 640, 720, skip_frac=0.1, skip_span=9, skip_max=3, drop_chain_frac=0.0),
+              J.random_job(8102, 580, 600, skip_frac=0.3, repeat_frac=0.05),
+              J.random_job(8103, 900, 300, skip_frac=0.03, skip_span=9, skip_max=2, drop_chain_frac=0.0)]
+    fillers = [J.random_job(8200 + k, 900, 900, skip_frac=0.15, skip_span=12, skip_max=2, drop_chain_frac=0.0) for k in range(64)]
+    for js in (probes, probes + fillers):
+        b = J.Batch(ctx, js, keep_matrices=True)
+        b.run()
+        res = b.fetch()
+        for i in range(len(probes)):
+            _cmp_job(b, i, js[i], res[i])
+        for i in range(len(probes), len(js), 9):
+            ref = oracle_lib.align_graphs(js[i])
+            assert res[i]["status"] == 0 and np.array_equal(res[i]["map1"], ref["map1"]) and np.array_equal(res[i]["map2"], ref["map2"]), i
+        b.close()
+
+
 def test_handoff_timeout_in_the_critical_path_kernel(ctx):
     """The same time-out path as below for a job swept by pgm_crit_kernel: band 3 never publishes its progress, the chain wavefront of band 4
     gives up, raises the abort flag, every wavefront of every worker leaves, the batch reports PGM_ERR_DEVICE — and runs clean afterwards."""
