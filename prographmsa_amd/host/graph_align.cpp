@@ -290,6 +290,35 @@ static void normalize(std::vector<double> &p) {  // p.norm()==0 ? p : p.normaliz
     for (double &v : p) v *= inv;
 }
 
+// The edge records of a merged graph in the order of the reference's ordered maps — by (to, from), of equal keys the smallest value
+// (updateEdge, GraphAlign.h:538-547) — without a comparison sort: the records arrive as a few runs that ascend in `to`, a node has a
+// handful of predecessors, so a counting pass over `to` and an insertion sort inside every node's few records does it in O(n).
+template <class Rec, class Value>
+static void order_records(std::vector<Rec> &v, size_t nnodes, Value value_of) {
+    std::vector<uint32_t> start(nnodes + 1, 0);
+    for (const Rec &r : v) start[r.to + 1]++;
+    for (size_t i = 0; i < nnodes; ++i) start[i + 1] += start[i];
+    std::vector<Rec> out(v.size());
+    {
+        std::vector<uint32_t> at(start.begin(), start.end() - 1);
+        for (const Rec &r : v) out[at[r.to]++] = r;
+    }
+    size_t w = 0;
+    for (size_t node = 0; node < nnodes; ++node) {
+        const size_t b = start[node], e = start[node + 1];
+        for (size_t i = b + 1; i < e; ++i) {
+            const Rec r = out[i];
+            size_t j = i;
+            while (j > b && (out[j - 1].from > r.from || (out[j - 1].from == r.from && value_of(out[j - 1]) > value_of(r)))) { out[j] = out[j - 1]; --j; }
+            out[j] = r;
+        }
+        for (size_t i = b; i < e; ++i)
+            if (i == b || out[i].from != out[i - 1].from) out[w++] = out[i];   // the cheapest of equal keys comes first
+    }
+    out.resize(w);
+    v.swap(out);
+}
+
 MergePlan planMerge(const Graph &g1, const Graph &g2, const std::vector<index_t> &mapping1, const std::vector<index_t> &mapping2) {
     const index_t NONE = (index_t)-1;
     MergePlan plan;
@@ -409,18 +438,8 @@ AncestralResult finishMerge(const Graph &g1, const Graph &g2, const MergePlan &p
             }
         }
     }
-    {
-        std::sort(edges.begin(), edges.end(), [](const Graph::EdgeRec &a, const Graph::EdgeRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.cost < c.cost); });
-        size_t w = 0;
-        for (size_t k = 0; k < edges.size(); ++k)   // the cheapest of equal keys comes first
-            if (w == 0 || edges[w - 1].to != edges[k].to || edges[w - 1].from != edges[k].from) edges[w++] = edges[k];
-        edges.resize(w);
-        std::sort(repeats.begin(), repeats.end(), [](const Graph::RepeatRec &a, const Graph::RepeatRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.units < c.units); });
-        w = 0;
-        for (size_t k = 0; k < repeats.size(); ++k)
-            if (w == 0 || repeats[w - 1].to != repeats[k].to || repeats[w - 1].from != repeats[k].from) repeats[w++] = repeats[k];
-        repeats.resize(w);
-    }
+    order_records(edges, nnodes, [](const Graph::EdgeRec &r) { return r.cost; });
+    order_records(repeats, nnodes, [](const Graph::RepeatRec &r) { return r.units; });
     result.graph = Graph(D, (index_t)nnodes, profiles, edges, repeats);
     return result;
 }
@@ -508,16 +527,8 @@ AncestralResult mergeGraphsIncremental(const Graph &anc_graph, const Graph &grap
             }
     }
     // (updateEdge, GraphAlign.h:538-547: of two edges with the same ends the cheaper one, of two repeats the one with fewer units)
-    std::sort(edges.begin(), edges.end(), [](const Graph::EdgeRec &a, const Graph::EdgeRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.cost < c.cost); });
-    size_t w = 0;
-    for (size_t k = 0; k < edges.size(); ++k)
-        if (w == 0 || edges[w - 1].to != edges[k].to || edges[w - 1].from != edges[k].from) edges[w++] = edges[k];
-    edges.resize(w);
-    std::sort(repeats.begin(), repeats.end(), [](const Graph::RepeatRec &a, const Graph::RepeatRec &c) { return a.to != c.to ? a.to < c.to : (a.from != c.from ? a.from < c.from : a.units < c.units); });
-    w = 0;
-    for (size_t k = 0; k < repeats.size(); ++k)
-        if (w == 0 || repeats[w - 1].to != repeats[k].to || repeats[w - 1].from != repeats[k].from) repeats[w++] = repeats[k];
-    repeats.resize(w);
+    order_records(edges, nnodes, [](const Graph::EdgeRec &r) { return r.cost; });
+    order_records(repeats, nnodes, [](const Graph::RepeatRec &r) { return r.units; });
     result.graph = Graph(D, (index_t)nnodes, profiles.data(), edges, repeats);
     return result;
 }
