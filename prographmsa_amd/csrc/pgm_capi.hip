@@ -259,6 +259,19 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
         const size_t rb = (size_t)8 << 20;
         if (!getenv("PGM_NO_STAGING_RESERVE") && hipHostMalloc(&p, rb, hipHostMallocDefault) == hipSuccess) { c->cache_ptr[pgm_ctx::C_HOST] = p; c->cache_bytes[pgm_ctx::C_HOST] = rb; }
         else (void)hipGetLastError();
+        // The device side of the same cache: 2.6 GB of the 288 (inputs 64 MB, prep outputs / codes 256 MB, DP cells 1.5 GB, results 8 MB,
+        // emission scores 768 MB, descriptors 4 MB) — what the levels of a 256 x 1000 pass take; a larger batch replaces a block.  On
+        // most hosts of the pool these six hipMalloc calls take 0.3 ms together; on some (or in some states of a host) the driver
+        // hands out device memory at ~30 ms per GB, and the first two levels of a pass then waited 50-70 ms for their buffers
+        // (DESIGN section 4): a runtime pays that when it starts, not in the middle of its first call.  PGM_NO_DEVICE_RESERVE=1: off.
+        if (!getenv("PGM_NO_STAGING_RESERVE") && !getenv("PGM_NO_DEVICE_RESERVE")) {
+            static const struct { int slot; size_t mb; } pool[] = {{pgm_ctx::C_IN, 64}, {pgm_ctx::C_WORK, 256}, {pgm_ctx::C_CELLS, 1536}, {pgm_ctx::C_OUT, 8}, {pgm_ctx::C_S, 768}, {pgm_ctx::C_SMALL, 4}};
+            for (const auto &e : pool) {
+                void *d = nullptr;
+                if (hipMalloc(&d, e.mb << 20) == hipSuccess) { c->cache_ptr[e.slot] = d; c->cache_bytes[e.slot] = e.mb << 20; }
+                else { (void)hipGetLastError(); break; }
+            }
+        }
     }
     *out = c;
     return PGM_OK;
