@@ -570,8 +570,13 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         });
         const auto tq0 = std::chrono::steady_clock::now();
         bool on_device = false;
-        if (!host_switches().host_merge) {
-            std::vector<pgm_merge_job> mj(L);
+        // (a resident pass: the graphs below need the plans only, not the profiles — the device batch of the node profiles runs on a
+        // thread of its own beside them)
+        std::thread merge_thread;
+        std::exception_ptr merge_error;
+        std::vector<pgm_merge_job> mj(L);   // (filled before the thread starts: the graphs section below releases the children)
+        bool all_on_device = true;
+        if (!host_switches().host_merge)
             for (size_t k = 0; k < L; ++k) {
                 Node &nd = nodes[level[k]];
                 const Graph &ga = nodes[nd.child[0]].res.graph, &gb = nodes[nd.child[1]].res.graph;
@@ -581,7 +586,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
                 j.P1 = pend[k].model1.P.data(); j.P2 = pend[k].model2.P.data();
                 j.k1 = plans[k].mapping1.data(); j.k2 = plans[k].mapping2.data(); j.g2_with_P1 = plans[k].g2_with_P1.data();
                 j.profiles = resident ? nullptr : profiles[k].data();
+                all_on_device = all_on_device && ga.devSites() && gb.devSites();
             }
+        auto merge_on_device = [&]() {
+        if (!host_switches().host_merge) {
             const auto tm0 = std::chrono::steady_clock::now();
             {
                 // the merges of a level are independent: dealt to the device contexts by the size of the merged graph
@@ -623,6 +631,10 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             }
             default_backend().seconds_merge_profiles += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
         }
+        };
+        if (resident && all_on_device && !host_switches().host_merge) merge_thread = std::thread([&]() { try { merge_on_device(); } catch (...) { merge_error = std::current_exception(); } });
+        else merge_on_device();
+        struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } merge_joiner{merge_thread};   // (also when the section below throws)
         const auto tq1 = std::chrono::steady_clock::now();
         std::atomic<long long> ns_merge(0), ns_extend(0);
         parallel_for(L, [&](size_t k) {
@@ -634,10 +646,9 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             result.score = ar[k].score;
             result.is_csprofile = false;
             result.n_tr_indels = ar[k].n_tr_indels + r1.n_tr_indels + r2.n_tr_indels;
-            if (!on_device) mergeProfilesHost(r1.graph, r2.graph, p.model1, p.model2, plans[k], profiles[k]);
+            if (!resident && !on_device) mergeProfilesHost(r1.graph, r2.graph, p.model1, p.model2, plans[k], profiles[k]);
             AncestralResult anc = finishMerge(r1.graph, r2.graph, plans[k], resident ? nullptr : profiles[k].data(), (*nd.tree)[0].getBranchSupport(), (*nd.tree)[1].getBranchSupport());
             result.graph = anc.graph;
-            if (resident) result.graph.setDevSites(dev_profiles[k]);
             const auto tk1 = std::chrono::steady_clock::now();
             extend_alignment(a, result, anc.mapping1, r1.aligned_sequences, L == 1);
             extend_alignment(a, result, anc.mapping2, r2.aligned_sequences, L == 1);
@@ -667,6 +678,11 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             p.cg2.reset();
             profiles[k] = std::vector<double>();
         });
+        if (merge_thread.joinable()) {
+            merge_thread.join();
+            if (merge_error) std::rethrow_exception(merge_error);
+        }
+        if (resident) for (size_t k = 0; k < L; ++k) nodes[level[k]].res.graph.setDevSites(dev_profiles[k]);
         if (cmdlineopts.earlyref_flag) early_refinement(a, nodes, level, model_factory, repeats && !repeats->empty());
         const auto tp3 = std::chrono::steady_clock::now();
         if (host_switches().profile)
