@@ -591,7 +591,7 @@ def main():
             "end_to_end": {"pgmsa_wall_s": stats["wall_s"], "init_s": stats.get("init_s"), "progressive_s": stats["progressive_s"], "align_call_s": stats["align_s"],
                            "fasta_identical_to_reference": (out_md5 == md5s.get("c3.out.fa")) if headline else None,
                            "progressive_s_of_3_runs": stats.get("progressive_s_of_3_runs"),
-                           "note": "the median of three runs of the product driver outside the timed region (without the job dump; all three under progressive_s_of_3_runs); progressive_s incl. host merges, H2D/D2H and every allocation beyond the context's start-up pool; init_s = HIP start-up + code object load + that pool (64 MB pinned staging, 2.6 GB of device buffers: pgm_ctx_create), before the stage clocks start and inside pgmsa_wall_s",
+                           "note": "the median of three runs of the product driver outside the timed region (without the job dump; all three under progressive_s_of_3_runs); progressive_s incl. host merges, H2D/D2H and every allocation beyond the context's start-up pool; init_s = HIP start-up + code object load + that pool (128 MB pinned staging, 3.4 GB of device buffers: pgm_ctx_create), before the stage clocks start and inside pgmsa_wall_s",
                            "default_flow": default_flow},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -82,8 +82,8 @@ typedef struct pgm_align_batch pgm_align_batch;
 int pgm_device_count(void);
 /* One context per device (streams, buffer cache, resident arena).  Creation is where the start-up costs are paid: the device code
  * is loaded (an empty launch), the copy path is warmed (1 MB each way), the library's host threads are started, and the context's
- * buffer cache is filled with a first set of blocks — 64 MB + 8 MB of pinned staging memory and 2.6 GB of device memory (what the
- * levels of a 256 x 1000 progressive pass need; a batch that needs more replaces a block).  PGM_NO_STAGING_RESERVE=1 /
+ * buffer cache is filled with a first set of blocks — 128 MB + 8 MB of pinned staging memory and 3.4 GB of device memory (what the
+ * levels of a 256 x 1000 or a 1024 x 600 progressive pass need; a batch that needs more replaces a block).  PGM_NO_STAGING_RESERVE=1 /
  * PGM_NO_DEVICE_RESERVE=1 in the environment: no such blocks, every batch allocates what it needs when it is created. */
 int pgm_ctx_create(int device, pgm_ctx **out);
 void pgm_ctx_destroy(pgm_ctx *ctx);

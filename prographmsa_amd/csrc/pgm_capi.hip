@@ -249,23 +249,23 @@ int pgm_ctx_create(int device, pgm_ctx **out) {
     // ... and the library's host threads (flattening, staging copies, first touch of pinned blocks): sixteen thread starts are 0.4 ms
     // of whatever call needs them first
     (void)lib_pool().run(64, 16u, [](size_t) {});
-    {   // ... and a first staging block for the inputs of a batch in the context's cache (64 MB: a level of 128 jobs of 1000 x 1000
-        // takes 37; a larger batch replaces it): allocating, touching and registering it is 0.8-1 ms of the first batch otherwise
+    {   // ... and a first staging block for the inputs of a batch in the context's cache (128 MB: a level of 128 jobs of 1000 x 1000
+        // takes 37, one of 512 jobs of 600 x 600 95; a larger batch replaces it — 4 ms for the release of a pinned block): allocating, touching and registering it is 0.8-1 ms of the first batch otherwise
         void *p = nullptr;
-        const size_t sb = (size_t)64 << 20;
+        const size_t sb = (size_t)128 << 20;
         if (!getenv("PGM_NO_STAGING_RESERVE") && pinned_alloc(sb, &p) == hipSuccess) { c->cache_ptr[pgm_ctx::C_HIN] = p; c->cache_bytes[pgm_ctx::C_HIN] = sb; }
         else (void)hipGetLastError();
         // (and for the results the kernels write over PCIe: 8 MB hold the mappings of 128 jobs of 1000 x 1000 four times over)
         const size_t rb = (size_t)8 << 20;
         if (!getenv("PGM_NO_STAGING_RESERVE") && hipHostMalloc(&p, rb, hipHostMallocDefault) == hipSuccess) { c->cache_ptr[pgm_ctx::C_HOST] = p; c->cache_bytes[pgm_ctx::C_HOST] = rb; }
         else (void)hipGetLastError();
-        // The device side of the same cache: 2.6 GB of the 288 (inputs 64 MB, prep outputs / codes 256 MB, DP cells 1.5 GB, results 8 MB,
-        // emission scores 768 MB, descriptors 4 MB) — what the levels of a 256 x 1000 pass take; a larger batch replaces a block.  On
+        // The device side of the same cache: 3.4 GB of the 288 (inputs 128 MB, prep outputs / codes 256 MB, DP cells 2 GB, results 8 MB,
+        // emission scores 1 GB, descriptors 4 MB) — what the levels of a 256 x 1000 or a 1024 x 600 pass take; a larger batch replaces a block.  On
         // most hosts of the pool these six hipMalloc calls take 0.3 ms together; on some (or in some states of a host) the driver
         // hands out device memory at ~30 ms per GB, and the first two levels of a pass then waited 50-70 ms for their buffers
         // (DESIGN section 4): a runtime pays that when it starts, not in the middle of its first call.  PGM_NO_DEVICE_RESERVE=1: off.
         if (!getenv("PGM_NO_STAGING_RESERVE") && !getenv("PGM_NO_DEVICE_RESERVE")) {
-            static const struct { int slot; size_t mb; } pool[] = {{pgm_ctx::C_IN, 64}, {pgm_ctx::C_WORK, 256}, {pgm_ctx::C_CELLS, 1536}, {pgm_ctx::C_OUT, 8}, {pgm_ctx::C_S, 768}, {pgm_ctx::C_SMALL, 4}};
+            static const struct { int slot; size_t mb; } pool[] = {{pgm_ctx::C_IN, 128}, {pgm_ctx::C_WORK, 256}, {pgm_ctx::C_CELLS, 2048}, {pgm_ctx::C_OUT, 8}, {pgm_ctx::C_S, 1024}, {pgm_ctx::C_SMALL, 4}};
             for (const auto &e : pool) {
                 void *d = nullptr;
                 if (hipMalloc(&d, e.mb << 20) == hipSuccess) { c->cache_ptr[e.slot] = d; c->cache_bytes[e.slot] = e.mb << 20; }
