@@ -226,6 +226,12 @@ int pgm_csprofile_load(pgm_ctx *ctx, uint32_t K, uint32_t ncols, const double *l
 int pgm_csprofile_create_batch(pgm_ctx *ctx, uint32_t nseq, const int8_t *syms,
                                const uint32_t *offs, const double *tau, const double *pi,
                                const double *p_uniform, double *out, const uint64_t *out_offs);
+/* The same with the profiles left in HBM (the leaf graphs of a resident pass, as pgm_resident_onehot for plain sequence graphs):
+ * dev[s] = the 20 x (L_s + 2) matrix of sequence s in the context's resident arena (valid until pgm_resident_reset), to be named by
+ * pgm_site_ref / pgm_merge_job; nothing is copied back. */
+int pgm_csprofile_create_batch_res(pgm_ctx *ctx, uint32_t nseq, const int8_t *syms,
+                                   const uint32_t *offs, const double *tau, const double *pi,
+                                   const double *p_uniform, const double **dev);
 float pgm_csprofile_last_kernel_ms(pgm_ctx *ctx);
 
 /* ---- (f3) DistanceFactoryML::computeDistance / computeMLDist — replaces reference

@@ -158,6 +158,16 @@ struct OracleBackend : Backend {
                                   lib.priors().data(), syms + offs[s], offs[s + 1] - offs[s], tau[s], pi,
                                   p_uniform + (size_t)s * 20, out + out_offs[s]);
     }
+    bool csprofile_create_batch_res(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double *tau, const double *pi,
+                                    const double *p_uniform, const double **dev, int w) override {
+        for (uint32_t s = 0; s < nseq; ++s) {
+            double *m = arena_alloc(w, (size_t)20 * (offs[s + 1] - offs[s] + 2));
+            pgmo_csprofile_create((uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(), lib.centre().data(),
+                                  lib.priors().data(), syms + offs[s], offs[s + 1] - offs[s], tau[s], pi, p_uniform + (size_t)s * 20, m);
+            dev[s] = m;
+        }
+        return true;
+    }
 };
 }  // namespace
 Backend &default_backend() {

@@ -63,7 +63,7 @@ EXPORTS = [
     "pgm_device_count", "pgm_ctx_create", "pgm_ctx_destroy", "pgm_last_error", "pgm_ctx_device_info",
     "pgm_align_graphs_batch", "pgm_align_batch_create", "pgm_align_batch_create_ex", "pgm_align_batch_create_res", "pgm_align_graphs_batch_res", "pgm_align_batch_run", "pgm_align_batch_fetch",
     "pgm_align_batch_destroy", "pgm_align_batch_cells", "pgm_align_batch_test_stall", "pgm_test_cu_shares", "pgm_align_batch_stage_times", "pgm_align_batch_job_times", "pgm_align_batch_time", "pgm_align_batch_read_matrices",
-    "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch",
+    "pgm_nw_pairs_batch", "pgm_nw_pairs_submit", "pgm_nw_pairs_wait", "pgm_nw_last_kernel_ms", "pgm_host_alloc", "pgm_host_free", "pgm_csprofile_load", "pgm_csprofile_create_batch", "pgm_csprofile_create_batch_res",
     "pgm_csprofile_last_kernel_ms", "pgm_mldist_batch", "pgm_prealigned_counts_batch", "pgm_kmer_cosine", "pgm_dist_last_kernel_ms",
     "pgm_merge_profiles_batch", "pgm_merge_profiles_batch_ex", "pgm_resident_reset", "pgm_resident_onehot", "pgm_resident_import", "pgm_merge_last_kernel_ms",
 ]
@@ -108,6 +108,8 @@ def _load():
         "pgm_csprofile_load": (C.c_int, [vp, u32, u32] + [C.POINTER(C.c_double)] * 3),
         "pgm_csprofile_create_batch": (C.c_int, [vp, u32, C.POINTER(C.c_int8), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 4
                                        + [C.POINTER(C.c_uint64)]),
+        "pgm_csprofile_create_batch_res": (C.c_int, [vp, u32, C.POINTER(C.c_int8), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 3
+                                           + [C.POINTER(C.POINTER(C.c_double))]),
         "pgm_csprofile_last_kernel_ms": (C.c_float, [vp]),
         "pgm_mldist_batch": (C.c_int, [vp, C.POINTER(pgm_mldist_model), u32, C.POINTER(i32), C.POINTER(u32)] + [C.POINTER(C.c_double)] * 3),
         "pgm_prealigned_counts_batch": (C.c_int, [vp, u32, u32, u32, C.POINTER(C.c_int8), u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.POINTER(u32)]),

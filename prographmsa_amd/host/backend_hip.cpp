@@ -127,6 +127,19 @@ struct HipBackend : Backend {
         int rc = pgm_csprofile_create_batch(ctx, nseq, syms, offs, tau, pi, p_uniform, out, out_offs);
         if (rc != PGM_OK) error("pgm_csprofile_create_batch failed (%d): %s", rc, pgm_last_error());
     }
+    bool csprofile_create_batch_res(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double *tau, const double *pi,
+                                    const double *p_uniform, const double **dev, int worker) override {
+        pgm_ctx *ctx = ctx_of(worker);
+        const size_t slot = (size_t)worker % ctxs.size();
+        if (loaded[slot] != &lib) {
+            int rc = pgm_csprofile_load(ctx, (uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(), lib.centre().data(), lib.priors().data());
+            if (rc != PGM_OK) error("pgm_csprofile_load failed (%d): %s", rc, pgm_last_error());
+            loaded[slot] = &lib;
+        }
+        int rc = pgm_csprofile_create_batch_res(ctx, nseq, syms, offs, tau, pi, p_uniform, dev);
+        if (rc != PGM_OK) error("pgm_csprofile_create_batch_res failed (%d): %s", rc, pgm_last_error());
+        return true;
+    }
 };
 }  // namespace
 

@@ -290,6 +290,9 @@ struct Backend {
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
                                         const uint64_t *out_offs, int worker = 0) = 0;
+    // ... left on the device of `worker` (resident pass): dev[s] = the 20 x (len + 2) matrix of sequence s; false = not available
+    virtual bool csprofile_create_batch_res(const class CSProfile &, uint32_t, const int8_t *, const uint32_t *, const double *, const double *,
+                                            const double *, const double **, int = 0) { return false; }
     int farm_workers = 0, farm_tiles = 0;   // what the last all-pairs farm used (logs / --stats)
     int farm_level_workers = 0, farm_leaf_workers = 0;   // most workers a guide-tree level's jobs / the leaves' profiles were dealt to
     bool resident_pass = false; int resident_imports = 0;   // the last progressive pass kept its profiles on the devices; matrices copied between them

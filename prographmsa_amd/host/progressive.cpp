@@ -417,27 +417,60 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
         // createProfile batch (SequenceGraph.h:111-121, CSProfile.cpp:175-225).
         if (a.kind != ALPHA_AA) error("context-specific profiles need the AA alphabet");
         const uint32_t ns = (uint32_t)leaves.size();
-        std::vector<int8_t> syms;
         std::vector<uint32_t> offs(ns + 1, 0);
         std::vector<uint64_t> out_offs(ns + 1, 0);
-        std::vector<double> tau(ns), p_uniform((size_t)ns * 20), pi;
+        std::vector<double> tau(ns), p_uniform((size_t)ns * 20), pi(20, 0.0);
+        std::vector<const sequence_t *> seqs(ns);
         for (uint32_t s = 0; s < ns; ++s) {
-            const Node &nd = nodes[leaves[s]];
-            const sequence_t &seq = sequences.at(nd.tree->getName());
-            for (int8_t c : seq) syms.push_back(a.isValid(c) ? (int8_t)a.value(c) : (int8_t)20);
-            offs[s + 1] = (uint32_t)syms.size();
-            out_offs[s + 1] = out_offs[s] + (uint64_t)20 * (seq.size() + 2);
-            Model m = model_factory.getModel(nd.tree->getBranchLength());
+            seqs[s] = &sequences.at(nodes[leaves[s]].tree->getName());
+            offs[s + 1] = offs[s] + (uint32_t)seqs[s]->size();
+            out_offs[s + 1] = out_offs[s] + (uint64_t)20 * (seqs[s]->size() + 2);
+        }
+        std::vector<int8_t> syms(offs[ns]);
+        parallel_for(ns, [&](size_t s) {   // (a model per leaf — its branch length —: P(t) from the eigen form, 20 us each)
+            int8_t *o = syms.data() + offs[s];
+            for (int8_t c : *seqs[s]) *o++ = a.isValid(c) ? (int8_t)a.value(c) : (int8_t)20;
+            Model m = model_factory.getModel(nodes[leaves[s]].tree->getBranchLength());
             tau[s] = m.divergence / 0.8;
-            pi = m.pi;
+            if (s == 0) pi = m.pi;   // (the same for every leaf)
             for (int i = 0; i < 20; ++i) {  // model.P * Constant(1/20)
                 double acc = 0;
                 for (int j = 0; j < 20; ++j) acc += m.P[i + 20 * j] * (1.0 / 20);
                 p_uniform[(size_t)s * 20 + i] = acc;
             }
+        });
+        bool on_device = false;
+        if (resident_pass) {   // the profile matrices stay where the leaf's subtree is aligned (as the one-hot leaves above)
+            Backend &be = default_backend();
+            on_device = true;
+            for (int w = 0; w < be.workers() && on_device; ++w) {
+                std::vector<uint32_t> mine;
+                for (uint32_t s = 0; s < ns; ++s) if (owner[(size_t)leaves[s]] == w) mine.push_back(s);
+                if (mine.empty()) continue;
+                std::vector<int8_t> sy;
+                std::vector<uint32_t> of(mine.size() + 1, 0);
+                std::vector<double> ta(mine.size()), pu(mine.size() * 20);
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    const uint32_t s = mine[k];
+                    sy.insert(sy.end(), syms.begin() + offs[s], syms.begin() + offs[s + 1]);
+                    of[k + 1] = (uint32_t)sy.size();
+                    ta[k] = tau[s];
+                    std::copy(p_uniform.begin() + (size_t)s * 20, p_uniform.begin() + (size_t)s * 20 + 20, pu.begin() + k * 20);
+                }
+                std::vector<const double *> dev(mine.size(), nullptr);
+                on_device = be.csprofile_create_batch_res(*csprofile, (uint32_t)mine.size(), sy.data(), of.data(), ta.data(), pi.data(), pu.data(), dev.data(), w);
+                if (!on_device) { if (w != 0) error("the backend could not build the leaf profiles on the device"); break; }
+                for (size_t k = 0; k < mine.size(); ++k) {
+                    Node &nd = nodes[leaves[mine[k]]];
+                    nd.res.graph = Graph(20, (index_t)seqs[mine[k]]->size() + 2, Graph::NoSites());
+                    nd.res.graph.setDevSites(dev[k]);
+                    nd.res.is_csprofile = true;
+                }
+            }
+            if (on_device) be.farm_leaf_workers = std::max(be.farm_leaf_workers, be.workers());
         }
-        std::vector<double> out(out_offs[ns]);
-        {
+        std::vector<double> out(on_device ? 0 : out_offs[ns]);
+        if (!on_device) {
             // the leaves are independent (SequenceGraph.h:111-121): dealt to the device contexts by length
             Backend &be = default_backend();
             std::vector<uint64_t> cost(ns);
@@ -468,7 +501,7 @@ ProgressiveAlignmentResult progressive_alignment(const Alphabet &a, const std::m
             }
             be.farm_leaf_workers = std::max(be.farm_leaf_workers, (int)shards.size());
         }
-        for (uint32_t s = 0; s < ns; ++s) {
+        for (uint32_t s = 0; s < ns && !on_device; ++s) {
             Node &nd = nodes[leaves[s]];
             index_t nn = (index_t)((out_offs[s + 1] - out_offs[s]) / 20);
             std::vector<double> sites(out.begin() + out_offs[s], out.begin() + out_offs[s + 1]);

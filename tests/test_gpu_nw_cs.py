@@ -152,6 +152,56 @@ def test_csprofile_matches_oracle(ctx):
         np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0)
 
 
+def test_csprofile_profiles_left_on_the_device(ctx):
+    """pgm_csprofile_create_batch_res (the leaf graphs of a resident pass with --cs_profile): the matrices stay in the context's
+    resident arena.  Two such leaves aligned through pgm_site_ref give the score bits and mappings of the same two graphs with the
+    host variant's columns uploaded the ordinary way — the kernel and its output are the same, only the destination differs."""
+    import prographmsa_amd as pg
+    from prographmsa_amd import jobs as J
+    rng = np.random.default_rng(5)
+    K, ncols = 23, 13
+    p = rng.gamma(0.3, 1.0, (K, ncols, 20)) + 1e-4
+    p /= p.sum(2, keepdims=True)
+    w = 1.3 * 0.9 ** np.abs(np.arange(ncols) - ncols // 2)
+    lp = np.zeros((K, ncols, 21))
+    lp[:, :, :20] = np.log(p) * w[None, :, None]
+    centre = p[:, ncols // 2, :].copy()
+    priors = np.log(rng.dirichlet(np.ones(K)))
+    lens = [83, 140]
+    seqs = [rng.integers(0, 21, L).astype(np.int8) for L in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    syms = np.concatenate(seqs).astype(np.int8)
+    out_offs = np.concatenate([[0], np.cumsum([20 * (L + 2) for L in lens])]).astype(np.uint64)
+    tau = rng.uniform(0.05, 0.9, len(lens))
+    pi = rng.dirichlet(np.ones(20) * 5)
+    pu = rng.dirichlet(np.ones(20), len(lens))
+    out = np.full(int(out_offs[-1]), np.nan)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    lpf, cf, prf, puf = [np.ascontiguousarray(a, np.float64).reshape(-1) for a in (lp, centre, priors, pu)]
+    pg.check(pg.lib.pgm_csprofile_load(ctx.handle, K, ncols, P(lpf, C.c_double), P(cf, C.c_double), P(prf, C.c_double)))
+    pg.check(pg.lib.pgm_csprofile_create_batch(ctx.handle, 2, P(syms, C.c_int8), P(offs, C.c_uint32), P(tau, C.c_double),
+                                               P(pi, C.c_double), P(puf, C.c_double), P(out, C.c_double), P(out_offs, C.c_uint64)))
+    dev = (C.POINTER(C.c_double) * 2)()
+    pg.check(pg.lib.pgm_resident_reset(ctx.handle))
+    pg.check(pg.lib.pgm_csprofile_create_batch_res(ctx.handle, 2, P(syms, C.c_int8), P(offs, C.c_uint32), P(tau, C.c_double),
+                                                   P(pi, C.c_double), P(puf, C.c_double), dev))
+    job = J.random_job(4343, lens[0] + 2, lens[1] + 2, dim=20, skip_frac=0.0, drop_chain_frac=0.0)
+    job.g1.sites = out[int(out_offs[0]): int(out_offs[1])].copy()
+    job.g2.sites = out[int(out_offs[1]): int(out_offs[2])].copy()
+    b = J.Batch(ctx, [job])
+    b.run()
+    want = b.fetch()[0]
+    b.close()
+    cj = J.CJobs([job])
+    r1 = (pg.pgm_site_ref * 1)(); r2 = (pg.pgm_site_ref * 1)()
+    r1[0].dev_sites, r1[0].node_map, r1[0].ncols = dev[0], None, lens[0] + 2
+    r2[0].dev_sites, r2[0].node_map, r2[0].ncols = dev[1], None, lens[1] + 2
+    pg.check(pg.lib.pgm_align_graphs_batch_res(ctx.handle, 1, cj.g1, cj.g2, cj.m, cj.sc, r1, r2, cj.out))
+    got = cj.results()[0]
+    assert want["status"] == 0 and np.float32(got["score"]).view(np.uint32) == np.float32(want["score"]).view(np.uint32)
+    assert np.array_equal(got["map1"], want["map1"]) and np.array_equal(got["map2"], want["map2"])
+
+
 def test_csprofile_config5_scale_sample(ctx):
     """BASELINE config 5 scale: the synthetic K = 4000 library and 1024 leaves x 600 residues of bench.py's `csprofile` record
     (same generator, same seeds); every 64th leaf is compared with the oracle (the library streams through LDS in 250 chunks)."""
