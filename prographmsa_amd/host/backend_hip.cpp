@@ -127,6 +127,14 @@ struct HipBackend : Backend {
         int rc = pgm_csprofile_create_batch(ctx, nseq, syms, offs, tau, pi, p_uniform, out, out_offs);
         if (rc != PGM_OK) error("pgm_csprofile_create_batch failed (%d): %s", rc, pgm_last_error());
     }
+    void csprofile_preload(const CSProfile &lib) override {
+        for (size_t slot = 0; slot < ctxs.size(); ++slot) {
+            if (loaded[slot] == &lib) continue;
+            int rc = pgm_csprofile_load(ctxs[slot], (uint32_t)lib.nprof(), (uint32_t)lib.ncols(), lib.lprofiles().data(), lib.centre().data(), lib.priors().data());
+            if (rc != PGM_OK) error("pgm_csprofile_load failed (%d): %s", rc, pgm_last_error());
+            loaded[slot] = &lib;
+        }
+    }
     bool csprofile_create_batch_res(const CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs, const double *tau, const double *pi,
                                     const double *p_uniform, const double **dev, int worker) override {
         pgm_ctx *ctx = ctx_of(worker);

@@ -290,6 +290,8 @@ struct Backend {
     virtual void csprofile_create_batch(const class CSProfile &lib, uint32_t nseq, const int8_t *syms, const uint32_t *offs,
                                         const double *tau, const double *pi, const double *p_uniform, double *out,
                                         const uint64_t *out_offs, int worker = 0) = 0;
+    // the profile library handed to every worker ahead of the first createProfile batch (start-up: before the clocks of the stages)
+    virtual void csprofile_preload(const class CSProfile &) {}
     // ... left on the device of `worker` (resident pass): dev[s] = the 20 x (len + 2) matrix of sequence s; false = not available
     virtual bool csprofile_create_batch_res(const class CSProfile &, uint32_t, const int8_t *, const uint32_t *, const double *, const double *,
                                             const double *, const double **, int = 0) { return false; }
